@@ -1,0 +1,12 @@
+"""latentblending_amd — MI355X-native latent-blending transition engine.
+
+Import surface mirrors the reference package (``latentblending/__init__.py:1-3``).
+"""
+from .blending_engine import BlendingEngine
+from .diffusers_holder import DiffusersHolder
+from .utils import (interpolate_spherical, add_frames_linear_interp, interpolate_linear,
+                    get_spacing, get_time, yml_load, yml_save)
+
+__all__ = ["BlendingEngine", "DiffusersHolder", "interpolate_spherical",
+           "add_frames_linear_interp", "interpolate_linear", "get_spacing", "get_time",
+           "yml_load", "yml_save"]

@@ -1,0 +1,522 @@
+"""``BlendingEngine`` — latent-blending transitions between two prompts.
+
+Drop-in for the reference class (``latentblending/blending_engine.py:19-789`` in
+/root/reference): same constructor, setters, ``run_transition`` / ``compute_latents*`` /
+``swap_forward`` / writers, same attribute names for the tree state
+(``tree_latents``, ``tree_fracts``, ``tree_final_imgs``, ``tree_idx_injection``,
+``tree_similarities``) and the same model-dependent defaults.
+
+What is different underneath:
+
+* tree policy lives in :mod:`latentblending_amd.tree`, schedules in
+  :mod:`latentblending_amd.planner` (both pure host code, pinned by golden vectors generated with
+  the reference's own functions);
+* every tensor operation on the path (parental-mix slerps, conditioning lerps, the denoising
+  loop, VAE decode, perceptual distance) is a gfx950 HIP kernel behind the C-ABI when the pipe is
+  a ``NativeSDXLPipe``;
+* with a native pipe and ``frontier_width > 1`` the greedy insertion loop evaluates the children
+  of the ``frontier_width`` widest gaps in ONE batched launch sequence and then commits them in
+  the reference's order — the committed tree is identical to the sequential one (a gap's child
+  does not depend on insertions elsewhere), unconsumed speculation is dropped at level end.
+"""
+from __future__ import annotations
+
+import os
+import platform
+import time
+from typing import List, Optional
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import planner
+from .diffusers_holder import DiffusersHolder, _is_native
+from .tree import UNSCORED, TransitionTree
+from .utils import interpolate_linear, interpolate_spherical
+
+try:  # progress bars are optional
+    from tqdm.auto import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x, **_):
+        return x
+
+
+class BlendingEngine:
+    def __init__(self, pipe: None, do_compile: bool = False,
+                 guidance_scale_mid_damper: float = 0.5, mid_compression_scaler: float = 1.2,
+                 metric=None, frontier_width: int = 1, verbose: bool = True):
+        """
+        Args:
+            pipe: SDXL pipeline (``NativeSDXLPipe`` for the gfx950 path, or any diffusers-like pipe).
+            do_compile: native pipe -> replay the UNet / VAE launch sequences from hipGraphs.
+                (The reference's stable-fast / triton compile does not exist here.)
+            guidance_scale_mid_damper: (0, 1]; lowers guidance towards the middle of the transition.
+            mid_compression_scaler: kept for signature compatibility (unused upstream as well).
+            metric: optional perceptual-distance callable ``metric(a, b)`` on ``[1,3,H,W]`` tensors
+                in [-1, 1]; default: the pipe's native LPIPS, else the ``lpips`` package.
+            frontier_width: number of gaps evaluated concurrently (native pipes only).
+        """
+        assert guidance_scale_mid_damper > 0 and guidance_scale_mid_damper <= 1.0, \
+            f"guidance_scale_mid_damper neees to be in interval (0,1], you provided {guidance_scale_mid_damper}"
+
+        self.verbose = verbose
+        self.dh = DiffusersHolder(pipe)
+        self.device = self.dh.device
+        self.set_dimensions()
+
+        self.guidance_scale_mid_damper = guidance_scale_mid_damper
+        self.mid_compression_scaler = mid_compression_scaler
+        self.frontier_width = int(frontier_width)
+        self.seed1 = 0
+        self.seed2 = 0
+        self.prompt1 = ""
+        self.prompt2 = ""
+
+        self._tree = TransitionTree()
+        self.idx_injection = []
+        self.tree_status = None
+        self.text_embedding1 = None
+        self.text_embedding2 = None
+        self.image1_lowres = None
+        self.image2_lowres = None
+        self.negative_prompt = None
+        self.stats = {}
+
+        self.set_guidance_scale()
+        self.multi_transition_img_first = None
+        self.multi_transition_img_last = None
+        self.dt_unet_step = 0
+        self.lpips = self._resolve_metric(metric)
+
+        self.set_prompt1("")
+        self.set_prompt2("")
+        self.set_branch1_crossfeed()
+        self.set_parental_crossfeed()
+        self.set_num_inference_steps()
+        self.benchmark_speed()
+        self.set_branching()
+
+        if do_compile:
+            if _is_native(self.dh.pipe):
+                self.dh.pipe.enable_graphs(True)
+            else:
+                self._say("do_compile: no compiler for non-native pipes on this platform; ignored")
+
+    # ------------------------------------------------------------------ tree state (API) ---
+    tree_latents = property(lambda s: s._tree.latents, lambda s, v: setattr(s._tree, "latents", v))
+    tree_fracts = property(lambda s: s._tree.fracts, lambda s, v: setattr(s._tree, "fracts", v))
+    tree_final_imgs = property(lambda s: s._tree.frames, lambda s, v: setattr(s._tree, "frames", v))
+    tree_idx_injection = property(lambda s: s._tree.idx_injection,
+                                  lambda s, v: setattr(s._tree, "idx_injection", v))
+    tree_similarities = property(lambda s: s._tree.similarities,
+                                 lambda s, v: setattr(s._tree, "similarities", v))
+
+    def _say(self, msg):
+        if self.verbose:
+            print(msg)
+
+    def _resolve_metric(self, metric):
+        if metric is not None:
+            return metric
+        native = getattr(self.dh.pipe, "lpips_metric", None)
+        if native is not None:
+            return native
+        import lpips  # the reference's dependency; absent -> ImportError, as upstream
+        net = lpips.LPIPS(net='alex')
+        return net if platform.system() == "Darwin" else net.cuda(self.device)
+
+    # ------------------------------------------------------------------ setters -----------
+    def benchmark_speed(self):
+        """Time one UNet step and one VAE decode; both feed the time-budget planner."""
+        self._say("starting speed benchmark...")
+        emb = self.dh.get_text_embedding("test")
+        start = self.dh.get_noise(np.random.randint(111111))
+        last = self.num_inference_steps - 1
+        self.dh.run_diffusion_sd_xl(text_embeddings=emb, latents_start=start,
+                                    return_image=False, idx_start=last)  # warm-up
+        self._sync()
+        t0 = time.time()
+        traj = self.dh.run_diffusion_sd_xl(text_embeddings=emb, latents_start=start,
+                                           return_image=False, idx_start=last)
+        self._sync()
+        self.dt_unet_step = time.time() - t0
+        t0 = time.time()
+        self.dh.latent2image(traj[-1])
+        self._sync()
+        self.dt_vae = time.time() - t0
+        self._say(f"time per unet iteration: {self.dt_unet_step} time for vae: {self.dt_vae}")
+
+    def _sync(self):
+        if _is_native(self.dh.pipe):
+            self.dh.pipe.synchronize()
+
+    def set_dimensions(self, size_output=None):
+        """(width, height) of the output; default 512² for turbo, 1024² otherwise."""
+        if size_output is None:
+            size_output = (512, 512) if self.dh.is_sdxl_turbo else (1024, 1024)
+        self.dh.set_dimensions(size_output)
+
+    def set_guidance_scale(self, guidance_scale=None):
+        if guidance_scale is None:
+            guidance_scale = 0.0 if self.dh.is_sdxl_turbo else 4.0
+        self.guidance_scale_base = guidance_scale
+        self.guidance_scale = guidance_scale
+        self.dh.guidance_scale = guidance_scale
+
+    def set_negative_prompt(self, negative_prompt):
+        """One negative prompt.  As upstream, prompts embedded before this call are not re-embedded."""
+        self.negative_prompt = negative_prompt
+        self.dh.set_negative_prompt(negative_prompt)
+
+    def set_guidance_mid_dampening(self, fract_mixing):
+        g = planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper,
+                                    fract_mixing)
+        self.guidance_scale = g
+        self.dh.guidance_scale = g
+
+    def set_branch1_crossfeed(self, crossfeed_power=0, crossfeed_range=0, crossfeed_decay=0):
+        """Crossfeed from the first anchor's trajectory into the second anchor (all in [0,1])."""
+        self.branch1_crossfeed_power = np.clip(crossfeed_power, 0, 1)
+        self.branch1_crossfeed_range = np.clip(crossfeed_range, 0, 1)
+        self.branch1_crossfeed_decay = np.clip(crossfeed_decay, 0, 1)
+
+    def set_parental_crossfeed(self, crossfeed_power=None, crossfeed_range=None, crossfeed_decay=None):
+        """Crossfeed from the parents into every mid branch.  Turbo defaults 1/1/1; for other pipes
+        the arguments are overridden with 0.3/0.6/0.9 exactly like upstream (blending_engine.py:200-203)."""
+        if self.dh.is_sdxl_turbo:
+            crossfeed_power = 1.0 if crossfeed_power is None else crossfeed_power
+            crossfeed_range = 1.0 if crossfeed_range is None else crossfeed_range
+            crossfeed_decay = 1.0 if crossfeed_decay is None else crossfeed_decay
+        else:
+            crossfeed_power, crossfeed_range, crossfeed_decay = 0.3, 0.6, 0.9
+        self.parental_crossfeed_power = np.clip(crossfeed_power, 0, 1)
+        self.parental_crossfeed_range = np.clip(crossfeed_range, 0, 1)
+        self.parental_crossfeed_decay = np.clip(crossfeed_decay, 0, 1)
+
+    def set_prompt1(self, prompt: str):
+        self.prompt1 = prompt.replace("_", " ")
+        self.text_embedding1 = self.get_text_embeddings(self.prompt1)
+
+    def set_prompt2(self, prompt: str):
+        self.prompt2 = prompt.replace("_", " ")
+        self.text_embedding2 = self.get_text_embeddings(self.prompt2)
+
+    def set_image1(self, image: Image):
+        self.image1_lowres = image
+
+    def set_image2(self, image: Image):
+        self.image2_lowres = image
+
+    def set_num_inference_steps(self, num_inference_steps=None):
+        if num_inference_steps is None:
+            num_inference_steps = 4 if self.dh.is_sdxl_turbo else 30
+        self.num_inference_steps = num_inference_steps
+        self.dh.set_num_inference_steps(num_inference_steps)
+
+    def set_branching(self, depth_strength=None, t_compute_max_allowed=None, nmb_max_branches=None):
+        """Plan ``list_idx_injection`` / ``list_nmb_stems``.  Turbo: one level (default index 2,
+        10 mid branches).  Otherwise: time budget (default 20 s) or a frame budget."""
+        if self.dh.is_sdxl_turbo:
+            assert t_compute_max_allowed is None, "time-based branching not supported for SDXL Turbo"
+            self.list_idx_injection, self.list_nmb_stems = planner.turbo_branching(
+                self.num_inference_steps, depth_strength, nmb_max_branches)
+            return
+        if depth_strength is None:
+            depth_strength = 0.5
+        if t_compute_max_allowed is None and nmb_max_branches is None:
+            t_compute_max_allowed = 20
+        elif t_compute_max_allowed is not None and nmb_max_branches is not None:
+            raise ValueError("Either specify t_compute_max_allowed or nmb_max_branches")
+        self.list_idx_injection, self.list_nmb_stems = self.get_time_based_branching(
+            depth_strength, t_compute_max_allowed, nmb_max_branches)
+
+    def get_time_based_branching(self, depth_strength, t_compute_max_allowed=None, nmb_max_branches=None):
+        return planner.time_based_branching(self.num_inference_steps, depth_strength,
+                                            self.dt_unet_step, self.dt_vae,
+                                            t_compute_max_allowed, nmb_max_branches)
+
+    # ------------------------------------------------------------------ transition --------
+    def run_transition(self, recycle_img1: Optional[bool] = False,
+                       recycle_img2: Optional[bool] = False,
+                       fixed_seeds: Optional[List[int]] = None):
+        """Compute the transition; returns the list of frames (PIL images), prompt1 -> prompt2.
+
+        recycle_img1 / recycle_img2: reuse the stored anchor trajectory (after ``swap_forward``).
+        fixed_seeds: two seeds for the anchors, or 'randomize'; ``None`` keeps the current seeds.
+        """
+        assert self.text_embedding1 is not None, 'Set the first text embedding with .set_prompt1(...) before'
+        assert self.text_embedding2 is not None, 'Set the second text embedding with .set_prompt2(...) before'
+
+        if fixed_seeds is not None:
+            if isinstance(fixed_seeds, str) and fixed_seeds == 'randomize':
+                fixed_seeds = list(np.random.randint(0, 1000000, 2).astype(np.int32))
+            else:
+                assert len(fixed_seeds) == 2, "Supply a list with len = 2"
+            self.seed1, self.seed2 = fixed_seeds[0], fixed_seeds[1]
+
+        steps = self.num_inference_steps
+        if recycle_img1 and len(self.tree_latents[0]) == steps:
+            first = self.tree_latents[0]
+        else:
+            first = self.compute_latents1()
+        if recycle_img2 and len(self.tree_latents[-1]) == steps:
+            last = self.tree_latents[-1]
+        else:
+            last = self.compute_latents2()
+
+        frames = self._decode_many([first[-1], last[-1]])
+        self._tree.reset(first, last, frames[0], frames[1])
+
+        use_frontier = self.frontier_width > 1 and _is_native(self.dh.pipe)
+        for level in tqdm(range(len(self.list_idx_injection)), disable=not self.verbose):
+            stems = int(self.list_nmb_stems[level])
+            idx_injection = int(self.list_idx_injection[level])
+            if use_frontier:
+                self._grow_level_frontier(idx_injection, stems)
+            else:
+                for _ in range(stems):
+                    fract, p1, p2 = self.get_mixing_parameters(idx_injection)
+                    self.set_guidance_mid_dampening(fract)
+                    branch = self.compute_latents_mix(fract, p1, p2, idx_injection)
+                    self.insert_into_tree(fract, idx_injection, branch)
+        return self.tree_final_imgs
+
+    def compute_latents1(self, return_image=False):
+        """Full trajectory of the first anchor (pure prompt1)."""
+        self._say("starting compute_latents1")
+        cond = self.get_mixed_conditioning(0)
+        t0 = time.time()
+        start = self.get_noise(self.seed1)
+        traj = self.run_diffusion(cond, latents_start=start, idx_start=0)
+        self.dt_unet_step = (time.time() - t0) / self.num_inference_steps
+        self.tree_latents[0] = traj
+        return self.dh.latent2image(traj[-1]) if return_image else traj
+
+    def compute_latents2(self, return_image=False):
+        """Full trajectory of the second anchor, optionally crossfed from the first."""
+        self._say("starting compute_latents2")
+        cond = self.get_mixed_conditioning(1)
+        start = self.get_noise(self.seed2)
+        if self.branch1_crossfeed_power > 0.0:
+            coeffs = planner.anchor_crossfeed_coeffs(
+                self.num_inference_steps, self.branch1_crossfeed_power,
+                self.branch1_crossfeed_range, self.branch1_crossfeed_decay)
+            traj = self.run_diffusion(cond, latents_start=start, idx_start=0,
+                                      list_latents_mixing=self.tree_latents[0],
+                                      mixing_coeffs=coeffs)
+        else:
+            traj = self.run_diffusion(cond, start)
+        self.tree_latents[-1] = traj
+        return self.dh.latent2image(traj[-1]) if return_image else traj
+
+    def _parental_mix(self, b_parent1, b_parent2, fract_parental):
+        """Slerp the two parents' trajectories step by step (``None`` where either has no latent)."""
+        lat1, lat2 = self.tree_latents[b_parent1], self.tree_latents[b_parent2]
+        have = [i for i in range(self.num_inference_steps)
+                if lat1[i] is not None and lat2[i] is not None]
+        mixed = [None] * self.num_inference_steps
+        if _is_native(self.dh.pipe) and have:
+            from .backend import get_backend
+            outs = get_backend().slerp_pairs([lat1[i] for i in have], [lat2[i] for i in have],
+                                             [fract_parental] * len(have))
+            for i, o in zip(have, outs):
+                mixed[i] = o
+        else:
+            for i in have:
+                mixed[i] = interpolate_spherical(lat1[i], lat2[i], fract_parental)
+        return mixed
+
+    def compute_latents_mix(self, fract_mixing, b_parent1, b_parent2, idx_injection):
+        """Trajectory of a mid branch at ``fract_mixing`` injected at step ``idx_injection`` from the
+        slerp of its parents' trajectories, with parental crossfeed."""
+        cond = self.get_mixed_conditioning(fract_mixing)
+        f1, f2 = self.tree_fracts[b_parent1], self.tree_fracts[b_parent2]
+        fract_parental = (fract_mixing - f1) / (f2 - f1)
+        mixed = self._parental_mix(b_parent1, b_parent2, fract_parental)
+        coeffs = planner.parental_crossfeed_coeffs(
+            self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
+            self.parental_crossfeed_range, self.parental_crossfeed_decay)
+        return self.run_diffusion(cond, latents_start=mixed[idx_injection - 1],
+                                  idx_start=idx_injection, list_latents_mixing=mixed,
+                                  mixing_coeffs=coeffs)
+
+    def get_mixing_parameters(self, idx_injection):
+        """(fract, parent1, parent2) of the next branch: midpoint of the least-similar gap."""
+        return self._tree.next_split(idx_injection)
+
+    def insert_into_tree(self, fract_mixing, idx_injection, list_latents):
+        """Decode the branch, measure it against both neighbours and commit it."""
+        frame = self.dh.latent2image(list_latents[-1])
+        lo, hi = self.get_closest_idx(fract_mixing)
+        left = self.get_lpips_similarity(frame, self.tree_final_imgs[lo])
+        right = self.get_lpips_similarity(frame, self.tree_final_imgs[hi])
+        self._tree.commit(fract_mixing, idx_injection, list_latents, frame, left, right)
+
+    def _decode_many(self, latents: list):
+        if _is_native(self.dh.pipe) and len(latents) > 1:
+            return self.dh.pipe.native_latent2image_batch(latents, "pil")
+        return [self.dh.latent2image(z) for z in latents]
+
+    # speculative frontier (native pipes) ---------------------------------------------------
+    def _grow_level_frontier(self, idx_injection: int, stems: int):
+        """Commit ``stems`` branches at this level, evaluating up to ``frontier_width`` gap
+        children per round in one batch.  Commit order == the sequential greedy order."""
+        pipe = self.dh.pipe
+        tree = self._tree
+        ready = {}  # (fract_left, fract_right) -> (fract, trajectory, frame, sim_left, sim_right)
+        remaining = stems
+        while remaining > 0:
+            # 1) commit everything the greedy order can already consume
+            progressed = True
+            while remaining > 0 and progressed:
+                progressed = False
+                gap = tree.widest_gap()
+                key = (tree.fracts[gap], tree.fracts[gap + 1])
+                if key in ready:
+                    fract, traj, frame, sl, sr = ready.pop(key)
+                    tree.commit(fract, idx_injection, traj, frame, sl, sr)
+                    remaining -= 1
+                    progressed = True
+            if remaining == 0:
+                break
+            # 2) speculate: the widest not-yet-evaluated gaps
+            if any(s is UNSCORED for s in tree.similarities):
+                order = [tree.widest_gap()]
+            else:  # descending, first maximum first (np.argmax tie-break)
+                order = list(np.argsort(-np.asarray(tree.similarities, dtype=np.float64),
+                                        kind="stable"))
+            picks = []
+            for gap in order:
+                key = (tree.fracts[int(gap)], tree.fracts[int(gap) + 1])
+                if key not in ready:
+                    picks.append(int(gap))
+                if len(picks) >= min(self.frontier_width, remaining):
+                    break
+            specs = []
+            for gap in picks:
+                fract, p1, p2 = tree.gap_child(gap, idx_injection)
+                g_eff = planner.damped_guidance(self.guidance_scale_base,
+                                                self.guidance_scale_mid_damper, fract)
+                f1, f2 = tree.fracts[p1], tree.fracts[p2]
+                specs.append(dict(
+                    gap=gap, fract=fract, guidance=g_eff,
+                    cond=self.get_mixed_conditioning(fract)[0],
+                    mixed=self._parental_mix(p1, p2, (fract - f1) / (f2 - f1)),
+                    coeffs=planner.parental_crossfeed_coeffs(
+                        self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
+                        self.parental_crossfeed_range, self.parental_crossfeed_decay)))
+            trajs = pipe.native_run_diffusion_batch(
+                [s["cond"] for s in specs], [s["mixed"][idx_injection - 1] for s in specs],
+                idx_injection, [s["mixed"] for s in specs], [s["coeffs"] for s in specs],
+                num_inference_steps=self.num_inference_steps,
+                guidance_scales=[s["guidance"] for s in specs])
+            frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil")
+            pairs = []
+            for s, frame in zip(specs, frames):
+                pairs.append((frame, tree.frames[s["gap"]]))
+                pairs.append((frame, tree.frames[s["gap"] + 1]))
+            sims = pipe.native_frame_distances(pairs)
+            for k, (s, traj, frame) in enumerate(zip(specs, trajs, frames)):
+                key = (tree.fracts[s["gap"]], tree.fracts[s["gap"] + 1])
+                ready[key] = (s["fract"], traj, frame, sims[2 * k], sims[2 * k + 1])
+            last = specs[-1]
+            self.guidance_scale = self.dh.guidance_scale = last["guidance"]
+        self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
+
+    # ------------------------------------------------------------------ plumbing ----------
+    def get_noise(self, seed):
+        return self.dh.get_noise(seed)
+
+    @torch.no_grad()
+    def run_diffusion(self, list_conditionings, latents_start: torch.Tensor = None,
+                      idx_start: int = 0, list_latents_mixing=None, mixing_coeffs=0.0,
+                      return_image: Optional[bool] = False):
+        """Pass-through to the holder; ``list_conditionings[0]`` is the embedding 4-tuple."""
+        self.dh.set_num_inference_steps(self.num_inference_steps)
+        assert type(list_conditionings) is list, "list_conditionings need to be a list"
+        return self.dh.run_diffusion_sd_xl(
+            text_embeddings=list_conditionings[0], latents_start=latents_start,
+            idx_start=idx_start, list_latents_mixing=list_latents_mixing,
+            mixing_coeffs=mixing_coeffs, return_image=return_image)
+
+    @torch.no_grad()
+    def get_mixed_conditioning(self, fract_mixing):
+        """Lerp every non-None member of the two embedding tuples; returned wrapped in a list."""
+        mixed = [None if a is None else interpolate_linear(a, b, fract_mixing)
+                 for a, b in zip(self.text_embedding1, self.text_embedding2)]
+        return [mixed]
+
+    @torch.no_grad()
+    def get_text_embeddings(self, prompt: str):
+        return self.dh.get_text_embedding(prompt)
+
+    # ------------------------------------------------------------------ output ------------
+    def write_imgs_transition(self, dp_img):
+        """Write the transition frames as ``lowres_img_XXXX.jpg`` into ``dp_img``."""
+        os.makedirs(dp_img, exist_ok=True)
+        for i, img in enumerate(self.tree_final_imgs):
+            leaf = img if isinstance(img, Image.Image) else Image.fromarray(np.asarray(img))
+            leaf.save(os.path.join(dp_img, f"lowres_img_{str(i).zfill(4)}.jpg"))
+
+    def write_movie_transition(self, fp_movie, duration_transition, fps=30):
+        """Linearly in-between the frames to ``duration_transition*fps`` frames and write a movie."""
+        from .movie import MovieSaver, fill_up_frames_linear_interpolation
+        frames = fill_up_frames_linear_interpolation(self.tree_final_imgs, duration_transition, fps)
+        if os.path.isfile(fp_movie):
+            os.remove(fp_movie)
+        saver = MovieSaver(fp_movie, fps=fps, shape_hw=[self.dh.height_img, self.dh.width_img])
+        for frame in tqdm(frames, disable=not self.verbose):
+            saver.write_frame(frame)
+        saver.finalize()
+
+    def get_state_dict(self):
+        """Scalar settings of the engine (the upstream list has a missing comma and names
+        attributes that do not exist, blending_engine.py:711-715; fixed here)."""
+        names = ['prompt1', 'prompt2', 'seed1', 'seed2', 'num_inference_steps', 'guidance_scale',
+                 'guidance_scale_mid_damper', 'mid_compression_scaler', 'negative_prompt',
+                 'branch1_crossfeed_power', 'branch1_crossfeed_range', 'branch1_crossfeed_decay',
+                 'parental_crossfeed_power', 'parental_crossfeed_range', 'parental_crossfeed_decay']
+        state = {}
+        for name in names:
+            if not hasattr(self, name):
+                continue
+            value = getattr(self, name)
+            if name in ('seed1', 'seed2'):
+                value = int(value)
+            elif name == 'guidance_scale' or isinstance(value, (np.floating, np.integer)):
+                value = float(value)
+            state[name] = value
+        state['width'] = self.dh.width_img
+        state['height'] = self.dh.height_img
+        return state
+
+    def swap_forward(self):
+        """Keyframe two becomes keyframe one (multi-transition chains)."""
+        self.tree_latents[0] = self.tree_latents[-1]
+        self.prompt1 = self.prompt2
+        self.text_embedding1 = self.text_embedding2
+        self.tree_final_imgs = []
+
+    # ------------------------------------------------------------------ metric ------------
+    def get_lpips_similarity(self, imgA, imgB):
+        """Perceptual distance of two frames (high = dissimilar)."""
+        pipe = self.dh.pipe
+        if _is_native(pipe) and self.lpips is getattr(pipe, "lpips_metric", None):
+            return pipe.native_frame_distances([(imgA, imgB)])[0]
+
+        def to_tensor(img):
+            t = torch.from_numpy(np.asarray(img)).float()
+            t = t.cuda(self.device) if str(self.device).startswith("cuda") else t
+            t = 2 * t / 255.0 - 1
+            return t.permute([2, 0, 1]).unsqueeze(0)
+        return float(self.lpips(to_tensor(imgA), to_tensor(imgB))[0][0][0][0])
+
+    def get_tree_similarities(self):
+        imgs = self.tree_final_imgs
+        return [self.get_lpips_similarity(imgs[i], imgs[i + 1]) for i in range(len(imgs) - 1)]
+
+    def get_closest_idx(self, fract_mixing: float):
+        """Indices of the two committed branches enclosing ``fract_mixing``
+        (e.g. 0.4 in [0, 0.3, 0.6, 1.0] -> (1, 2))."""
+        return self._tree.neighbours(fract_mixing)
