@@ -1,0 +1,148 @@
+/*
+ * lb_hip.h — C-ABI of liblbhip.so, the gfx950 (MI355X) kernel library behind
+ * latentblending_amd.
+ *
+ * The reference (lunarring/latentblending) has NO FFI boundary of its own: it is pure Python and
+ * reaches the device only through third-party wheels.  This header is the
+ * boundary we define for its hot path; every entry point names the reference call site whose
+ * device work it replaces (paths relative to /root/reference).  A maintainer of the reference
+ * would bind these with ctypes exactly as latentblending_amd/hip/lib.py does.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers unless a parameter says "host";
+ *   - every launcher takes the hipStream_t as `void* stream`, never allocates, never
+ *     synchronises (hipGraph-capturable) and returns hipError_t as int (0 = success);
+ *     lb_last_error_string() describes the last failure on the calling thread;
+ *   - fp16 tensors are IEEE binary16 (`lb_half` = uint16_t storage); activations are NHWC
+ *     ([B, H, W, C] == [B*H*W tokens, C]); weights are [N][K] row-major with K = KH*KW*Cin for
+ *     convolutions ((ky, kx, cin) order).
+ */
+#ifndef LB_HIP_H
+#define LB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t lb_half;
+
+/* ---- library ------------------------------------------------------------------------- */
+int lb_version(void);
+const char* lb_last_error_string(void);
+int lb_device_info(int device, int* cu_count, long* lds_per_cu, char* arch, int arch_len);
+
+/* ---- latent mixing (latentblending/utils.py:29-71 interpolate_spherical; called from
+ *      blending_engine.py:449 parental mix and diffusers_holder.py:324 crossfeed) -------- */
+/* host arrays of device pointers; fracts is a HOST array of doubles; out dtype = f16 for the
+ * f16 variant, f32 for f32 and f64 inputs (utils.py:47-50,66-69). */
+int lb_slerp_pairs_f16(const void* const* p0, const void* const* p1, void* const* out,
+                       const double* fracts, int npairs, long n, void* stream);
+int lb_slerp_pairs_f32(const void* const* p0, const void* const* p1, void* const* out,
+                       const double* fracts, int npairs, long n, void* stream);
+int lb_slerp_pairs_f64(const void* const* p0, const void* const* p1, void* const* out,
+                       const double* fracts, int npairs, long n, void* stream);
+/* contiguous batch [npairs][n] with device-side fracts: the HBM-roofline form (6 B/element). */
+int lb_slerp_batched_f16(const void* p0, const void* p1, void* out, const double* fracts_dev,
+                         long npairs, long n, void* stream);
+
+/* latentblending/utils.py:97 interpolate_linear on tensors (blending_engine.py:650) */
+int lb_lerp_f16(const void* p0, const void* p1, void* out, long n, double fract, void* stream);
+int lb_lerp_f32(const void* p0, const void* p1, void* out, long n, double fract, void* stream);
+
+/* ---- scheduler (diffusers_holder.py:330 scale_model_input, :347-349 CFG combine,
+ *      :356 scheduler.step — diffusers Euler / Euler-ancestral) ------------------------- */
+/* params_dev: float[batch][8] = {sigma_from, sigma_next, sigma_up, guidance, dt, -, -, -} */
+int lb_scale_model_input_f16(const void* x, void* out, const float* params_dev, long per_sample,
+                             int batch, int dup_for_cfg, void* stream);
+int lb_euler_step_f16(const void* x, const void* eps, const void* noise, void* out,
+                      const float* params_dev, long per_sample, int batch, int cfg, int ancestral,
+                      void* stream);
+
+/* ---- dense contractions (every nn.Linear / nn.Conv2d of the UNet at
+ *      diffusers_holder.py:336, of the VAE decoder at :135 and of LPIPS-Alex at
+ *      blending_engine.py:756) ----------------------------------------------------------- */
+enum {
+    LB_GEMM_OUT_F32 = 1,     /* C is float32 (VAE residual stream) */
+    LB_GEMM_RES_F32 = 2,     /* residual is float32 */
+    LB_GEMM_GEGLU = 4,       /* W = [h rows | gate rows], C[M, N/2] = h * gelu(gate) */
+    LB_GEMM_TRANS_OUT = 8,   /* store C^T: C[n*ldc + m] */
+    LB_GEMM_SILU = 16,       /* SiLU after bias/residual */
+    LB_GEMM_RELU = 32        /* ReLU after bias/residual */
+};
+
+typedef struct LbGemmParams {
+    const lb_half* A;        /* [M][lda] activations, or NHWC image for conv */
+    const lb_half* W;        /* [N][ldw] */
+    void* C;                 /* [M][ldc] f16 (default) / f32 */
+    const float* bias;       /* [N] or NULL */
+    const void* residual;    /* [M][ldr] f16 / f32 or NULL */
+    const lb_half* rowvec;   /* [M / rows_per_batch][ld_rowvec]: per-sample vector added to every
+                                row of that sample (time-embedding projection) or NULL */
+    float* partial;          /* split-K workspace (lb_gemm_workspace_bytes) or NULL = no split */
+    int M, N, K;
+    int lda, ldw, ldc, ldr, ld_rowvec, rows_per_batch;
+    float alpha;             /* 0 is read as 1 */
+    int flags;
+    /* implicit-GEMM convolution: A is [B][Hin][Win][ldx] NHWC, M = B*Hout*Wout */
+    int conv;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
+    int ups;                 /* 1: nearest-2x upsample of the input fused into the gather */
+    int ldx;                 /* pixel stride in elements (>= Cin) */
+    int splitk;              /* set by the launcher */
+} LbGemmParams;
+
+int lb_gemm_f16(const LbGemmParams* params, void* stream);
+long lb_gemm_workspace_bytes(int M, int N);
+void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1/2/3 and split-K */
+
+/* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached
+ *      from diffusers_holder.py:336 and :135) ------------------------------------------- */
+/* x: [B][HW][ldx] fp16 (or fp32 when x_is_f32); y: [B][HW][ldy] fp16 = GN(x)*gamma+beta, then
+ * SiLU when `silu`.  workspace: lb_groupnorm_workspace_bytes(B, groups). */
+long lb_groupnorm_workspace_bytes(int B, int groups);
+int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace,
+                      int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,
+                      int x_is_f32, void* stream);
+int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int M, int C,
+                     int ldx, int ldy, float eps, void* stream);
+
+/* ---- attention (AttnProcessor2_0 / scaled_dot_product_attention inside the UNet call at
+ *      diffusers_holder.py:336; VAE mid-block attention at :135) ------------------------ */
+typedef struct LbAttnParams {
+    const lb_half* Q;    /* element (b, q, h, d) at Q[(b*Sq + q)*ldq + h*64 + d] */
+    const lb_half* K;    /* element (b, k, h, d) at K[(b*Skv + k)*ldk + h*64 + d] */
+    const lb_half* Vt;   /* element (h, d, b, k) at Vt[(h*64 + d)*ldvt + b*Skv + k]  (V transposed) */
+    lb_half* O;          /* like Q with ldo */
+    int B, H, Sq, Skv, Skv_valid;   /* keys >= Skv_valid are masked; Skv % 8 == 0 */
+    int ldq, ldk, ldvt, ldo;
+    float scale;         /* 1/sqrt(64) */
+} LbAttnParams;
+int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
+int lb_softmax_rows_f16(void* x, int M, int N, int ld, float scale, void* stream);
+
+/* ---- small kernels ----------------------------------------------------------------- */
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0): [cos | sin] */
+int lb_sinusoid_f16(const float* vals_dev, int rows, int per_row, int val_stride, int dim, void* out,
+                    int ld_out, int col_off, void* stream);
+/* torch.cat along channels: dst[r][dst_off + c] = src[r][c] */
+int lb_copy_cols_f16(const void* src, void* dst, long rows, int cols, int ld_src, int ld_dst,
+                     int dst_off, void* stream);
+int lb_cast_f16_to_f32(const void* x, void* y, long n, void* stream);
+int lb_cast_f32_to_f16(const void* x, void* y, long n, void* stream);
+int lb_nchw_to_nhwc_f16(const void* x, void* y, int B, int C, int HW, int ld, float mul, void* stream);
+int lb_nhwc_to_nchw_f16(const void* x, void* y, int B, int C, int HW, int ld, void* stream);
+/* VaeImageProcessor.postprocess (diffusers_holder.py:141): uint8 HWC frames on device */
+int lb_postprocess_u8(const void* x, void* out_u8, long pixels, int ld, int x_is_f32, void* stream);
+/* lpips.LPIPS(net='alex') pieces (blending_engine.py:744-758) */
+int lb_lpips_prep_u8(const void* img_u8, void* out_f16, long pixels, void* stream);
+int lb_maxpool3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
+int lb_lpips_tap(const void* feats, const float* lin, const int* pairs_dev, float* acc,
+                 float* workspace, int npairs, int HW, int C, void* stream);
+int lb_fill_f32(void* x, long n, float v, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LB_HIP_H */

@@ -1,0 +1,62 @@
+"""Build liblbhip.so (gfx950) in-tree with hipcc.  No cmake, no torch headers: the library is a
+plain C-ABI shared object loaded with ctypes (include/lb_hip.h is the contract)."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.join(os.path.dirname(HERE), "hip")
+LIB_PATH = os.path.join(OUT_DIR, "liblbhip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on",
+         "-Wno-unused-result", "-I", HERE]
+
+
+def sources():
+    return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def _needs(obj, deps):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+    headers = [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
+    if _needs(obj, [os.path.join(HERE, src)] + headers):
+        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    return obj
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    if force:
+        for f in os.listdir(os.path.join(HERE, "build")):
+            os.remove(os.path.join(HERE, "build", f))
+    with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(_compile, sources()))
+    if _needs(LIB_PATH, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    if verbose:
+        print(f"[lb build] {LIB_PATH} ({os.path.getsize(LIB_PATH) / 1e6:.1f} MB)")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

@@ -1,0 +1,350 @@
+// MFMA GEMM / implicit-GEMM convolution for gfx950 (fp16 operands, fp32 accumulate).
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T )
+//
+// One kernel family serves every dense contraction of the SDXL UNet / VAE decoder / LPIPS net:
+//   * Linear layers (A = tokens x channels, NHWC activations are already [B*H*W, C]),
+//   * 3x3 / kxk convolutions as implicit GEMM: the A-loader gathers NHWC pixels on the fly
+//     (K index = (ky*KW + kx)*Cin + c), with stride, zero padding and an optional fused
+//     nearest-2x upsample of the input (UNet/VAE upsamplers),
+//   * GEGLU (the block computes matching h / gate column groups and stores h*gelu(gate)),
+//   * epilogues: alpha, bias[n], per-sample row vector (time-embedding add), residual add
+//     (fp16 or fp32), fp16 / fp32 / transposed stores, split-K partial slabs.
+//
+// Tiling (wave64, 4 waves as 2x2): BMxBNx64 block tile, v_mfma_f32_16x16x32_f16, operands
+// swapped (a = W fragment, b = A fragment) so that each lane owns 4 CONSECUTIVE output columns
+// of one row -> 8-byte stores and vector bias/residual loads.  LDS tiles are [rows][64] halves
+// (128-B rows) with the 16-B chunk index XOR-swizzled by (row & 7) so ds_read_b128 fragment
+// reads spread over the 64 banks.  Global->register->LDS staging is software-pipelined one K-tile
+// ahead (loads issued before the MFMAs of the current tile, LDS written after them, one barrier
+// per K-tile, two LDS buffers).
+//
+// Replaces (third party, reached from /root/reference/latentblending/diffusers_holder.py:336
+// and :135): every torch.nn.Linear / Conv2d inside diffusers' UNet2DConditionModel and
+// AutoencoderKL decoder, and the AlexNet convolutions of lpips (blending_engine.py:756).
+#include "lb_common.h"
+#include "lb_gemm.h"
+
+#define BK 64
+
+template <int BM, int BN, bool CONV, bool GEGLU>
+__global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
+    constexpr int AI = BM * 8 / 256;        // 16-B chunks of A per thread per K-tile
+    constexpr int WI = BN * 8 / 256;
+    constexpr int TM = BM / 32;             // 16-row fragments per wave along M
+    constexpr int TN = BN / 32;
+    __shared__ __attribute__((aligned(16))) f16 lds[2 * (BM + BN) * BK];
+    f16* const As = lds;
+    f16* const Ws = lds + 2 * BM * BK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int g = lane >> 4, l16 = lane & 15;
+
+    const int n_blocks = GEGLU ? (p.N / 2 + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
+    // XCD-aware remap: consecutive block ids land on different XCDs (id % 8); give each XCD a
+    // contiguous run of tiles so that neighbours sharing A rows / W panels hit the same L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int block_n = bid % n_blocks, block_m = bid / n_blocks;
+    const int m0 = block_m * BM;
+    const int n0 = GEGLU ? block_n * (BN / 2) : block_n * BN;
+
+    // split-K range of this block
+    const int k_tiles_total = (p.K + BK - 1) / BK;
+    const int tiles_per_split = (k_tiles_total + p.splitk - 1) / p.splitk;
+    const int kt_begin = blockIdx.z * tiles_per_split;
+    int kt_end = kt_begin + tiles_per_split;
+    if (kt_end > k_tiles_total) kt_end = k_tiles_total;
+    const int nkt = kt_end - kt_begin;
+
+    const int slot = tid & 7;               // logical 16-B chunk (8 halves) within the K-tile
+    const int row0 = tid >> 3;              // first tile row this thread stages (then +32)
+
+    // ---- per-thread A source description --------------------------------------------------
+    long a_off[AI];                         // plain: row offset; conv: batch base offset
+    int a_iy[AI], a_ix[AI];
+    bool a_ok[AI];
+    int ci = 0, ky = 0, kx = 0;             // conv: decomposition of this thread's k index
+    int kcur = kt_begin * BK + slot * 8;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + row0 + i * 32;
+        a_ok[i] = m < p.M;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_off[i] = (long)b * p.Hin * p.Win * p.ldx;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+        } else {
+            a_off[i] = (long)m * p.lda;
+            a_iy[i] = a_ix[i] = 0;
+        }
+    }
+    if (CONV) {
+        const int tap = kcur / p.Cin;
+        ci = kcur - tap * p.Cin;
+        ky = tap / p.KW;
+        kx = tap - ky * p.KW;
+    }
+    // ---- per-thread W source rows ---------------------------------------------------------
+    long w_off[WI];
+    bool w_ok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int tr = row0 + i * 32;
+        int n;
+        if (GEGLU) {
+            const int sub = tr >> 4;
+            n = (sub & 1) * (p.N / 2) + n0 + (sub >> 1) * 16 + (tr & 15);
+            w_ok[i] = (n0 + (sub >> 1) * 16 + (tr & 15)) < p.N / 2;
+        } else {
+            n = n0 + tr;
+            w_ok[i] = n < p.N;
+        }
+        w_off[i] = (long)n * p.ldw;
+    }
+
+    f16x8 a_reg[AI], w_reg[WI];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int hin_eff = p.Hin << p.ups, win_eff = p.Win << p.ups;
+
+    auto load_tile = [&]() {
+        const bool k_ok = kcur < p.K;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            a_reg[i] = zero8;
+            if (CONV) {
+                const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                if (a_ok[i] && k_ok && iy >= 0 && iy < hin_eff && ix >= 0 && ix < win_eff)
+                    a_reg[i] = *reinterpret_cast<const f16x8*>(
+                        p.A + a_off[i] + ((long)(iy >> p.ups) * p.Win + (ix >> p.ups)) * p.ldx + ci);
+            } else {
+                if (a_ok[i] && k_ok)
+                    a_reg[i] = *reinterpret_cast<const f16x8*>(p.A + a_off[i] + kcur);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            w_reg[i] = zero8;
+            if (w_ok[i] && k_ok) w_reg[i] = *reinterpret_cast<const f16x8*>(p.W + w_off[i] + kcur);
+        }
+        // advance this thread's k state to the next K-tile
+        kcur += BK;
+        if (CONV) {
+            ci += BK;
+            while (ci >= p.Cin) {
+                ci -= p.Cin;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int r = row0 + i * 32;
+            *reinterpret_cast<f16x8*>(As + buf * BM * BK + r * BK + ((slot ^ (r & 7)) << 3)) = a_reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int r = row0 + i * 32;
+            *reinterpret_cast<f16x8*>(Ws + buf * BN * BK + r * BK + ((slot ^ (r & 7)) << 3)) = w_reg[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nkt > 0) {
+        load_tile();
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < nkt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nkt) load_tile();       // global loads in flight under the MFMAs below
+        const f16* Ab = As + buf * BM * BK + (wave_m * (BM / 2)) * BK;
+        const f16* Wb = Ws + buf * BN * BK + (wave_n * (BN / 2)) * BK;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 af[TM], wf[TN];
+            const int chunk = s * 4 + g;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = i * 16 + l16;
+                af[i] = *reinterpret_cast<const f16x8*>(Ab + r * BK + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = j * 16 + l16;
+                wf[j] = *reinterpret_cast<const f16x8*>(Wb + r * BK + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------
+    // lane owns C[m][n .. n+3] with m = frag row (lane&15), n = frag col 4*g + r
+    if (p.splitk > 1) {
+        float* slab = p.partial + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wave_m * (BM / 2) + i * 16 + l16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wave_n * (BN / 2) + j * 16 + 4 * g;
+                if (n < p.N) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wave_m * (BM / 2) + i * 16 + l16;
+        if (m >= p.M) continue;
+        const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
+        if (GEGLU) {
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int n = n0 + (wave_n * (BN / 64) + (j >> 1)) * 16 + 4 * g;   // output column
+                if (n >= p.N / 2) continue;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float h = acc[i][j][r] * p.alpha, gt = acc[i][j + 1][r] * p.alpha;
+                    if (p.bias) { h += p.bias[n + r]; gt += p.bias[p.N / 2 + n + r]; }
+                    o[r] = (f16)(h * lb_gelu_erf(gt));
+                }
+                *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wave_n * (BN / 2) + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                lb_gemm_store4(p, m, n, bidx, acc[i][j]);
+            }
+        }
+    }
+}
+
+// Sum split-K slabs and run the same epilogue.
+__global__ void gemm_splitk_reduce_kernel(const LbGemmParams p) {
+    const long quads = (long)p.M * (p.N / 4);
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += stride) {
+        const int m = (int)(q / (p.N / 4));
+        const int n = (int)(q - (long)m * (p.N / 4)) * 4;
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < p.splitk; ++z)
+            s += *reinterpret_cast<const f32x4*>(p.partial + ((long)z * p.M + m) * p.N + n);
+        lb_gemm_store4(p, m, n, p.rowvec ? m / p.rows_per_batch : 0, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
+    if (p.conv) {
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, true, false>), grid, dim3(256), 0, stream, p);
+    } else if (geglu) {
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, false, true>), grid, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, false, false>), grid, dim3(256), 0, stream, p);
+    }
+}
+
+static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64
+static int g_force_splitk = 0;    // 0 auto
+extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
+
+extern "C" long lb_gemm_workspace_bytes(int M, int N) {
+    // enough for the largest split the heuristic can pick (<= 16 slabs)
+    return (long)16 * M * N * (long)sizeof(float);
+}
+
+extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream_) {
+    LbGemmParams p = *pp;
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
+    LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_gemm_f16: empty problem");
+    LB_REQUIRE(p.K % 8 == 0 && p.ldw % 8 == 0, "lb_gemm_f16: K and ldw must be multiples of 8");
+    LB_REQUIRE(p.N % 4 == 0 && (geglu ? p.N % 8 == 0 : true), "lb_gemm_f16: N must be a multiple of 4");
+    LB_REQUIRE(p.ldc % 4 == 0 || (p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: ldc must be a multiple of 4");
+    if (p.conv) {
+        LB_REQUIRE(p.Cin % 8 == 0 && p.ldx % 8 == 0, "lb_gemm_f16: conv Cin/ldx must be multiples of 8");
+        LB_REQUIRE(p.K == p.KH * p.KW * p.Cin, "lb_gemm_f16: conv K != KH*KW*Cin");
+        LB_REQUIRE(p.M % (p.Hout * p.Wout) == 0, "lb_gemm_f16: conv M must be B*Hout*Wout");
+    } else {
+        LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
+    }
+    if (p.alpha == 0.f) p.alpha = 1.f;
+    const int n_eff = geglu ? p.N / 2 : p.N;
+
+    // tile choice: the largest tile that still gives >= ~1 block per CU; small grids fall back to
+    // 64x64 and are widened with split-K so that weight streaming is spread over the chip.
+    auto blocks = [&](int bm, int bn) {
+        const int bn_eff = geglu ? bn / 2 : bn;
+        return (long)((p.M + bm - 1) / bm) * ((n_eff + bn_eff - 1) / bn_eff);
+    };
+    int tile = g_force_tile;
+    if (!tile) {
+        if (blocks(128, 128) >= 224) tile = 1;
+        else if (blocks(128, 64) >= 224) tile = 2;
+        else tile = 3;
+    }
+    const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
+    const long nblk = blocks(bm, bn);
+    int splitk = 1;
+    if (!geglu && p.partial != nullptr) {
+        const int k_tiles = (p.K + BK - 1) / BK;
+        if (g_force_splitk) splitk = g_force_splitk;
+        else if (nblk < 160) {
+            splitk = (int)((256 + nblk - 1) / nblk);
+            const int max_by_k = k_tiles / 4 > 0 ? k_tiles / 4 : 1;   // >= 4 K-tiles per slice
+            if (splitk > max_by_k) splitk = max_by_k;
+            if (splitk > 16) splitk = 16;
+        }
+        if (splitk > k_tiles) splitk = k_tiles;
+        if (splitk < 1) splitk = 1;
+    }
+    p.splitk = splitk;
+
+    dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
+    if (tile == 1) launch_variant<128, 128>(p, grid, stream);
+    else if (tile == 2) launch_variant<128, 64>(p, grid, stream);
+    else launch_variant<64, 64>(p, grid, stream);
+    int rc = lb_check_launch("lb_gemm_f16");
+    if (rc) return rc;
+    if (splitk > 1) {
+        const long quads = (long)p.M * (p.N / 4);
+        long gsz = (quads + 255) / 256;
+        if (gsz > 2048) gsz = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, stream, p);
+        rc = lb_check_launch("lb_gemm_f16(split-K reduce)");
+    }
+    return rc;
+}

@@ -1,0 +1,62 @@
+// Common device/host helpers for the gfx950 kernels of liblbhip.so.
+// Written for CDNA4 only: wave = 64 lanes, MFMA 16x16x32 f16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define LB_WAVE 64
+
+typedef _Float16 f16;
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Last launch error is kept per process (C-ABI: lb_last_error_string()).
+extern "C" const char* lb_last_error_string(void);
+void lb_set_error(const char* what, hipError_t e);
+
+static inline int lb_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) lb_set_error(what, e);
+    return (int)e;
+}
+
+#define LB_REQUIRE(cond, what)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            lb_set_error(what, hipErrorInvalidValue);            \
+            return (int)hipErrorInvalidValue;                    \
+        }                                                        \
+    } while (0)
+
+__device__ __forceinline__ float lb_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, LB_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ double lb_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, LB_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float lb_wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, LB_WAVE));
+    return v;
+}
+
+// f64 -> f16 with a single rounding (round-to-odd f64->f32, then RN f32->f16).
+__device__ __forceinline__ f16 lb_f64_to_f16(double x) {
+    float f = __double2float_rz(x);
+    if ((double)f != x) f = __uint_as_float(__float_as_uint(f) | 1u);
+    return (f16)f;
+}
+
+__device__ __forceinline__ float lb_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float lb_gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}

@@ -1,0 +1,249 @@
+// Small coalesced elementwise / gather kernels of the UNet, VAE and LPIPS paths on gfx950:
+// sinusoidal embeddings, strided column copies (skip-connection concat), casts, VAE output
+// quantisation, LPIPS input scaling, 3x3/2 max-pool and the LPIPS distance reduction.
+//
+// Replaces (third party, reached from the reference call sites in parentheses):
+//   Timesteps / get_timestep_embedding           (diffusers_holder.py:336)
+//   torch.cat([hidden, skip], dim=1)             (diffusers_holder.py:336)
+//   VaeImageProcessor.postprocess                (diffusers_holder.py:141)
+//   lpips ScalingLayer / max_pool2d / normalize_tensor / spatial_average (blending_engine.py:756)
+#include "lb_common.h"
+
+static unsigned grid_for(long items, int block = 256, long cap = 2048) {
+    long g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+// out[r][col_off + j*dim + k] = (k < dim/2 ? cos : sin)(vals[r*per_row + j] * 10000^(-k'/half))
+__global__ void sinusoid_kernel(const float* __restrict__ vals, int rows, int per_row, int dim,
+                                f16* __restrict__ out, int ld_out, int col_off, int val_stride) {
+    const int half = dim >> 1;
+    const long total = (long)rows * per_row * dim;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % dim);
+        const long rj = i / dim;
+        const int j = (int)(rj % per_row), r = (int)(rj / per_row);
+        const int kk = k < half ? k : k - half;
+        const float freq = expf(-9.21034037197618f * (float)kk / (float)half);   // ln(10000)
+        const float ang = vals[(long)r * val_stride + j] * freq;
+        out[(long)r * ld_out + col_off + j * dim + k] = (f16)(k < half ? cosf(ang) : sinf(ang));
+    }
+}
+
+extern "C" int lb_sinusoid_f16(const float* vals_dev, int rows, int per_row, int val_stride, int dim,
+                               void* out, int ld_out, int col_off, void* stream) {
+    LB_REQUIRE(rows > 0 && per_row > 0 && dim > 0 && dim % 2 == 0, "lb_sinusoid_f16: sizes");
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(grid_for((long)rows * per_row * dim)), dim3(256), 0,
+                       (hipStream_t)stream, vals_dev, rows, per_row, dim, (f16*)out, ld_out, col_off,
+                       val_stride);
+    return lb_check_launch("lb_sinusoid_f16");
+}
+
+// dst[r][dst_off + c] = src[r][c], c < cols (multiple of 8), 16-B vectors
+__global__ void copy_cols_kernel(const f16* __restrict__ src, f16* __restrict__ dst, long rows, int cols,
+                                 int ld_src, int ld_dst, int dst_off) {
+    const int vecs = cols >> 3;
+    const long items = rows * vecs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / vecs;
+        const int v = (int)(i - r * vecs);
+        *reinterpret_cast<f16x8*>(dst + r * ld_dst + dst_off + v * 8) =
+            *reinterpret_cast<const f16x8*>(src + r * ld_src + v * 8);
+    }
+}
+
+extern "C" int lb_copy_cols_f16(const void* src, void* dst, long rows, int cols, int ld_src, int ld_dst,
+                                int dst_off, void* stream) {
+    LB_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && dst_off % 8 == 0,
+               "lb_copy_cols_f16: cols / ld / offset multiples of 8");
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)src, (f16*)dst, rows, cols, ld_src, ld_dst, dst_off);
+    return lb_check_launch("lb_copy_cols_f16");
+}
+
+__global__ void cast_f16_f32_kernel(const f16* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+__global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (f16)x[i];
+}
+extern "C" int lb_cast_f16_to_f32(const void* x, void* y, long n, void* stream) {
+    hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (float*)y, n);
+    return lb_check_launch("lb_cast_f16_to_f32");
+}
+extern "C" int lb_cast_f32_to_f16(const void* x, void* y, long n, void* stream) {
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (f16*)y, n);
+    return lb_check_launch("lb_cast_f32_to_f16");
+}
+
+// NCHW fp16 latent [B][C][HW] <-> NHWC fp16 [B][HW][ld] (C small: 4), with an optional scalar
+// multiply on the way in (latents / scaling_factor before the VAE, diffusers_holder.py:135).
+__global__ void nchw_to_nhwc_kernel(const f16* __restrict__ x, f16* __restrict__ y, int B, int C, int HW,
+                                    int ld, float mul) {
+    const long total = (long)B * HW * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld);
+        const long bp = i / ld;
+        const int px = (int)(bp % HW), b = (int)(bp / HW);
+        y[i] = c < C ? (f16)((float)x[((long)b * C + c) * HW + px] * mul) : (f16)0.f;
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const f16* __restrict__ x, f16* __restrict__ y, int B, int C, int HW, int ld) {
+    const long total = (long)B * C * HW;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % HW);
+        const long bc = i / HW;
+        const int c = (int)(bc % C), b = (int)(bc / C);
+        y[i] = x[((long)b * HW + px) * ld + c];
+    }
+}
+extern "C" int lb_nchw_to_nhwc_f16(const void* x, void* y, int B, int C, int HW, int ld, float mul, void* stream) {
+    LB_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C, "lb_nchw_to_nhwc_f16: sizes");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)B * HW * ld)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, (f16*)y, B, C, HW, ld, mul == 0.f ? 1.f : mul);
+    return lb_check_launch("lb_nchw_to_nhwc_f16");
+}
+extern "C" int lb_nhwc_to_nchw_f16(const void* x, void* y, int B, int C, int HW, int ld, void* stream) {
+    LB_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C, "lb_nhwc_to_nchw_f16: sizes");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)B * C * HW)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, (f16*)y, B, C, HW, ld);
+    return lb_check_launch("lb_nhwc_to_nchw_f16");
+}
+
+// VAE output [B][HW][ld] (fp32 or fp16, channels 0..2) -> uint8 [B][HW][3]:
+// round_half_even(clamp(x/2 + 0.5, 0, 1) * 255)
+template <typename T>
+__global__ void postprocess_u8_kernel(const T* __restrict__ x, uint8_t* __restrict__ out, long pixels, int ld) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels * 3; i += (long)gridDim.x * blockDim.x) {
+        const long px = i / 3;
+        const int c = (int)(i - px * 3);
+        float v = (float)x[px * ld + c] / 2.f + 0.5f;
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i] = (uint8_t)rintf(v * 255.f);
+    }
+}
+extern "C" int lb_postprocess_u8(const void* x, void* out_u8, long pixels, int ld, int x_is_f32, void* stream) {
+    LB_REQUIRE(pixels > 0 && ld >= 3, "lb_postprocess_u8: sizes");
+    if (x_is_f32)
+        hipLaunchKernelGGL((postprocess_u8_kernel<float>), dim3(grid_for(pixels * 3)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (uint8_t*)out_u8, pixels, ld);
+    else
+        hipLaunchKernelGGL((postprocess_u8_kernel<f16>), dim3(grid_for(pixels * 3)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16*)x, (uint8_t*)out_u8, pixels, ld);
+    return lb_check_launch("lb_postprocess_u8");
+}
+
+// ---- LPIPS helpers ------------------------------------------------------------------------
+// uint8 frame [N][HW][3] -> fp16 NHWC [N][HW][8]: ((2*x/255 - 1) - shift_c) / scale_c, channels 3..7 zero
+__global__ void lpips_prep_kernel(const uint8_t* __restrict__ img, f16* __restrict__ out, long pixels) {
+    const float shift[3] = {-.030f, -.088f, -.188f}, scale[3] = {.458f, .448f, .450f};
+    for (long px = (long)blockIdx.x * blockDim.x + threadIdx.x; px < pixels; px += (long)gridDim.x * blockDim.x) {
+        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = 2.f * (float)img[px * 3 + c] / 255.f - 1.f;
+            o[c] = (f16)((v - shift[c]) / scale[c]);
+        }
+        *reinterpret_cast<f16x8*>(out + px * 8) = o;
+    }
+}
+extern "C" int lb_lpips_prep_u8(const void* img_u8, void* out_f16, long pixels, void* stream) {
+    hipLaunchKernelGGL(lpips_prep_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)img_u8, (f16*)out_f16, pixels);
+    return lb_check_launch("lb_lpips_prep_u8");
+}
+
+// NHWC max-pool k3 s2 (no padding): [N][H][W][C] -> [N][Ho][Wo][C], Ho = (H-3)/2+1
+__global__ void maxpool3s2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int N, int H, int W, int C,
+                                  int Ho, int Wo) {
+    const int vecs = C >> 3;
+    const long items = (long)N * Ho * Wo * vecs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(i % vecs);
+        long r = i / vecs;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (f16)-65504.f;
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const f16x8 t = *reinterpret_cast<const f16x8*>(x + (((long)n * H + oy * 2 + dy) * W + ox * 2 + dx) * C + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = t[e] > m[e] ? t[e] : m[e];
+            }
+        *reinterpret_cast<f16x8*>(y + (((long)n * Ho + oy) * Wo + ox) * C + v * 8) = m;
+    }
+}
+extern "C" int lb_maxpool3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    LB_REQUIRE(N > 0 && H >= 3 && W >= 3 && C % 8 == 0, "lb_maxpool3s2_nhwc_f16: sizes");
+    const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for((long)N * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo);
+    return lb_check_launch("lb_maxpool3s2_nhwc_f16");
+}
+
+// One LPIPS tap: feats [N][HW][C]; for every pair (ia, ib):
+//   d = mean_px sum_c lin[c] * (fa/(|fa|+eps) - fb/(|fb|+eps))^2
+// One wave per pixel; per-block partial sums are folded by a single thread in fixed order
+// (deterministic).  acc[pair] += d  (acc is zeroed by the caller before the first tap).
+__global__ void __launch_bounds__(256) lpips_tap_kernel(const f16* __restrict__ feats, const float* __restrict__ lin,
+                                                        const int* __restrict__ pairs, float* __restrict__ block_part,
+                                                        int HW, int C) {
+    __shared__ float red[4];
+    const int pair = blockIdx.y;
+    const f16* fa = feats + (long)pairs[pair * 2 + 0] * HW * C;
+    const f16* fb = feats + (long)pairs[pair * 2 + 1] * HW * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int px = blockIdx.x * 4 + wave; px < HW; px += gridDim.x * 4) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float a = (float)fa[(long)px * C + c], b = (float)fb[(long)px * C + c];
+            sa += a * a; sb += b * b;
+        }
+        sa = lb_wave_sum(sa); sb = lb_wave_sum(sb);
+        const float ia = 1.f / (sqrtf(sa) + 1e-10f), ib = 1.f / (sqrtf(sb) + 1e-10f);
+        float d = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float t = (float)fa[(long)px * C + c] * ia - (float)fb[(long)px * C + c] * ib;
+            d += lin[c] * t * t;
+        }
+        acc += lb_wave_sum(d);
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_part[(long)pair * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void lpips_fold_kernel(const float* __restrict__ block_part, float* __restrict__ acc, int nblk, float inv_hw) {
+    const int pair = blockIdx.x;
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nblk; ++i) s += (double)block_part[(long)pair * nblk + i];
+        acc[pair] += (float)(s * inv_hw);
+    }
+}
+extern "C" int lb_lpips_tap(const void* feats, const float* lin, const int* pairs_dev, float* acc, float* workspace,
+                            int npairs, int HW, int C, void* stream) {
+    LB_REQUIRE(npairs > 0 && HW > 0 && C > 0, "lb_lpips_tap: sizes");
+    int nblk = (HW + 3) / 4;
+    if (nblk > 128) nblk = 128;
+    hipLaunchKernelGGL(lpips_tap_kernel, dim3(nblk, npairs), dim3(256), 0, (hipStream_t)stream, (const f16*)feats, lin,
+                       pairs_dev, workspace, HW, C);
+    int rc = lb_check_launch("lb_lpips_tap");
+    if (rc) return rc;
+    hipLaunchKernelGGL(lpips_fold_kernel, dim3(npairs), dim3(64), 0, (hipStream_t)stream, workspace, acc, nblk, 1.f / (float)HW);
+    return lb_check_launch("lb_lpips_tap(fold)");
+}
+
+// generic fill (zero LPIPS accumulators etc. without a runtime memset node)
+__global__ void fill_f32_kernel(float* x, long n, float v) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
+}
+extern "C" int lb_fill_f32(void* x, long n, float v, void* stream) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (float*)x, n, v);
+    return lb_check_launch("lb_fill_f32");
+}

@@ -1,0 +1,331 @@
+// Latent-mixing primitives for gfx950: whole-tensor slerp (float64 reductions), conditioning
+// lerp, scheduler input scaling, CFG combine + Euler / Euler-ancestral update.
+// All are HBM/L2-bound elementwise kernels: 16 B per lane, coalesced, wave-shuffle reductions.
+//
+// Reference behaviour (paths relative to /root/reference):
+//   slerp           latentblending/utils.py:29-71      (called at blending_engine.py:449 and
+//                                                        diffusers_holder.py:324)
+//   lerp            latentblending/utils.py:97          (blending_engine.py:650)
+//   scale / step    diffusers_holder.py:330, 347-349, 356 (diffusers Euler schedulers)
+#include "lb_common.h"
+
+#define LB_MAX_PAIRS 16
+
+struct SlerpPairs {
+    const void* p0[LB_MAX_PAIRS];
+    const void* p1[LB_MAX_PAIRS];
+    void* out[LB_MAX_PAIRS];
+    double fract[LB_MAX_PAIRS];
+};
+
+template <typename T> struct OutOf { typedef float type; };
+template <> struct OutOf<f16> { typedef f16 type; };
+
+template <typename O> __device__ __forceinline__ O lb_from_f64(double x);
+template <> __device__ __forceinline__ f16 lb_from_f64<f16>(double x) { return lb_f64_to_f16(x); }
+template <> __device__ __forceinline__ float lb_from_f64<float>(double x) { return (float)x; }
+
+// Block-wide sum of three doubles; result valid in every thread.
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red) {
+    a = lb_wave_sum(a); b = lb_wave_sum(b); c = lb_wave_sum(c);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (lane == 0) { red[wave * 3 + 0] = a; red[wave * 3 + 1] = b; red[wave * 3 + 2] = c; }
+    __syncthreads();
+    if (wave == 0) {
+        double x = lane < nw ? red[lane * 3 + 0] : 0.0;
+        double y = lane < nw ? red[lane * 3 + 1] : 0.0;
+        double z = lane < nw ? red[lane * 3 + 2] : 0.0;
+        x = lb_wave_sum(x); y = lb_wave_sum(y); z = lb_wave_sum(z);
+        if (lane == 0) { red[48] = x; red[49] = y; red[50] = z; }
+    }
+    __syncthreads();
+    a = red[48]; b = red[49]; c = red[50];
+}
+
+// weights of p0 / p1 from <p0,p1>, |p0|^2, |p1|^2 — the reference's formula, in float64.
+__device__ __forceinline__ void slerp_weights(double dot, double n0sq, double n1sq, double fract,
+                                              double& w0, double& w1) {
+    double c = dot / (sqrt(n0sq) * sqrt(n1sq));
+    const double lim = 1.0 - 1e-7;
+    c = c > lim ? lim : (c < -lim ? -lim : c);   // NaN passes through, as torch.clamp does
+    const double theta = acos(c);
+    const double st = sin(theta);
+    const double tt = theta * fract;
+    w0 = sin(theta - tt) / st;
+    w1 = sin(tt) / st;
+}
+
+template <typename T, int VEC>
+__device__ __forceinline__ void slerp_body(const T* __restrict__ p0, const T* __restrict__ p1,
+                                           typename OutOf<T>::type* __restrict__ out, long n,
+                                           double fract, T* stage0, T* stage1, bool staged,
+                                           double* red) {
+    typedef typename OutOf<T>::type O;
+    typedef T VT __attribute__((ext_vector_type(VEC)));
+    typedef O VO __attribute__((ext_vector_type(VEC)));
+    const long nvec = n / VEC;
+    double dot = 0, s0 = 0, s1 = 0;
+    for (long i = threadIdx.x; i < nvec; i += blockDim.x) {
+        VT a = *reinterpret_cast<const VT*>(p0 + i * VEC);
+        VT b = *reinterpret_cast<const VT*>(p1 + i * VEC);
+        if (staged) {
+            *reinterpret_cast<VT*>(stage0 + i * VEC) = a;
+            *reinterpret_cast<VT*>(stage1 + i * VEC) = b;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double x = (double)a[j], y = (double)b[j];
+            dot += x * y; s0 += x * x; s1 += y * y;
+        }
+    }
+    for (long i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x) {
+        const double x = (double)p0[i], y = (double)p1[i];
+        dot += x * y; s0 += x * x; s1 += y * y;
+    }
+    block_sum3(dot, s0, s1, red);
+    double w0, w1;
+    slerp_weights(dot, s0, s1, fract, w0, w1);
+    for (long i = threadIdx.x; i < nvec; i += blockDim.x) {
+        VT a, b;
+        if (staged) {
+            a = *reinterpret_cast<const VT*>(stage0 + i * VEC);
+            b = *reinterpret_cast<const VT*>(stage1 + i * VEC);
+        } else {
+            a = *reinterpret_cast<const VT*>(p0 + i * VEC);
+            b = *reinterpret_cast<const VT*>(p1 + i * VEC);
+        }
+        VO r;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            r[j] = lb_from_f64<O>(__dadd_rn(__dmul_rn((double)a[j], w0), __dmul_rn((double)b[j], w1)));
+        *reinterpret_cast<VO*>(out + i * VEC) = r;
+    }
+    for (long i = nvec * VEC + threadIdx.x; i < n; i += blockDim.x)
+        out[i] = lb_from_f64<O>(__dadd_rn(__dmul_rn((double)p0[i], w0), __dmul_rn((double)p1[i], w1)));
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(512) slerp_pairs_kernel(SlerpPairs args, long n) {
+    __shared__ double red[64];
+    const int b = blockIdx.x;
+    slerp_body<T, VEC>((const T*)args.p0[b], (const T*)args.p1[b],
+                       (typename OutOf<T>::type*)args.out[b], n, args.fract[b], nullptr, nullptr,
+                       false, red);
+}
+
+// Contiguous batch [npairs][n]; inputs optionally staged in LDS so HBM is read exactly once
+// (6 B/element for fp16: read p0, read p1, write out).
+template <typename T, int VEC>
+__global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict__ p0,
+                                                             const T* __restrict__ p1,
+                                                             typename OutOf<T>::type* __restrict__ out,
+                                                             const double* __restrict__ fracts,
+                                                             long n, int staged) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* red = reinterpret_cast<double*>(smem);            // 64 doubles = 512 B
+    T* stage0 = reinterpret_cast<T*>(smem + 512);
+    T* stage1 = stage0 + n;
+    const long b = blockIdx.x;
+    slerp_body<T, VEC>(p0 + b * n, p1 + b * n, out + b * n, n, fracts[b], stage0, stage1,
+                       staged != 0, red);
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T>
+static int slerp_pairs_launch(const void* const* p0, const void* const* p1, void* const* out,
+                              const double* fracts, int npairs, long n, hipStream_t stream) {
+    for (int base = 0; base < npairs; base += LB_MAX_PAIRS) {
+        const int cnt = npairs - base < LB_MAX_PAIRS ? npairs - base : LB_MAX_PAIRS;
+        SlerpPairs args;
+        bool vec_ok = true;
+        for (int i = 0; i < cnt; ++i) {
+            args.p0[i] = p0[base + i]; args.p1[i] = p1[base + i]; args.out[i] = out[base + i];
+            args.fract[i] = fracts[base + i];
+            vec_ok = vec_ok && aligned16(args.p0[i]) && aligned16(args.p1[i]) && aligned16(args.out[i]);
+        }
+        constexpr int VEC = 16 / sizeof(T) > 8 ? 8 : 16 / sizeof(T);
+        if (vec_ok)
+            hipLaunchKernelGGL((slerp_pairs_kernel<T, VEC>), dim3(cnt), dim3(512), 0, stream, args, n);
+        else
+            hipLaunchKernelGGL((slerp_pairs_kernel<T, 1>), dim3(cnt), dim3(512), 0, stream, args, n);
+        int rc = lb_check_launch("lb_slerp_pairs");
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int lb_slerp_pairs_f16(const void* const* p0, const void* const* p1, void* const* out,
+                                  const double* fracts, int npairs, long n, void* stream) {
+    LB_REQUIRE(npairs >= 0 && n > 0, "lb_slerp_pairs_f16: bad sizes");
+    return slerp_pairs_launch<f16>(p0, p1, out, fracts, npairs, n, (hipStream_t)stream);
+}
+
+extern "C" int lb_slerp_pairs_f32(const void* const* p0, const void* const* p1, void* const* out,
+                                  const double* fracts, int npairs, long n, void* stream) {
+    LB_REQUIRE(npairs >= 0 && n > 0, "lb_slerp_pairs_f32: bad sizes");
+    return slerp_pairs_launch<float>(p0, p1, out, fracts, npairs, n, (hipStream_t)stream);
+}
+
+extern "C" int lb_slerp_pairs_f64(const void* const* p0, const void* const* p1, void* const* out,
+                                  const double* fracts, int npairs, long n, void* stream) {
+    LB_REQUIRE(npairs >= 0 && n > 0, "lb_slerp_pairs_f64: bad sizes");
+    return slerp_pairs_launch<double>(p0, p1, out, fracts, npairs, n, (hipStream_t)stream);
+}
+
+extern "C" int lb_slerp_batched_f16(const void* p0, const void* p1, void* out,
+                                    const double* fracts_dev, long npairs, long n, void* stream) {
+    LB_REQUIRE(npairs > 0 && n > 0 && n % 8 == 0, "lb_slerp_batched_f16: n must be a multiple of 8");
+    LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_slerp_batched_f16: 16-B alignment");
+    const size_t stage_bytes = (size_t)n * 2 * sizeof(f16);
+    const int staged = stage_bytes <= 128 * 1024 ? 1 : 0;
+    const size_t smem = 512 + (staged ? stage_bytes : 0);
+    auto kern = slerp_batched_kernel<f16, 8>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 512 + 128 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)npairs), dim3(512), smem, (hipStream_t)stream,
+                       (const f16*)p0, (const f16*)p1, (f16*)out, fracts_dev, n, staged);
+    return lb_check_launch("lb_slerp_batched_f16");
+}
+
+// ------------------------------------------------------------------------------------------
+// lerp:  out = half(half(wa*p0) + half(wb*p1))  — the rounding sequence of
+// "(1 - f) * p0 + f * p1" on fp16 tensors with fp32 op-math (utils.py:97).
+// ------------------------------------------------------------------------------------------
+__global__ void lerp_f16_kernel(const f16* __restrict__ p0, const f16* __restrict__ p1,
+                                f16* __restrict__ out, long n, float wa, float wb) {
+    const long nvec = n >> 3;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const f16x8 a = *reinterpret_cast<const f16x8*>(p0 + i * 8);
+        const f16x8 b = *reinterpret_cast<const f16x8*>(p1 + i * 8);
+        f16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const f16 ta = (f16)((float)a[j] * wa);
+            const f16 tb = (f16)((float)b[j] * wb);
+            r[j] = (f16)((float)ta + (float)tb);
+        }
+        *reinterpret_cast<f16x8*>(out + i * 8) = r;
+    }
+    for (long i = (nvec << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const f16 ta = (f16)((float)p0[i] * wa);
+        const f16 tb = (f16)((float)p1[i] * wb);
+        out[i] = (f16)((float)ta + (float)tb);
+    }
+}
+
+__global__ void lerp_f32_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                float* __restrict__ out, long n, float wa, float wb) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = __fadd_rn(__fmul_rn(p0[i], wa), __fmul_rn(p1[i], wb));
+}
+
+static unsigned ew_grid(long work_items, int block) {
+    long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;   // grid-stride above 8 blocks/CU x 256 CUs
+    return (unsigned)g;
+}
+
+extern "C" int lb_lerp_f16(const void* p0, const void* p1, void* out, long n, double fract,
+                           void* stream) {
+    LB_REQUIRE(n > 0, "lb_lerp_f16: n");
+    LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_lerp_f16: 16-B alignment");
+    hipLaunchKernelGGL(lerp_f16_kernel, dim3(ew_grid((n + 7) / 8, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const f16*)p0, (const f16*)p1, (f16*)out, n,
+                       (float)(1.0 - fract), (float)fract);
+    return lb_check_launch("lb_lerp_f16");
+}
+
+extern "C" int lb_lerp_f32(const void* p0, const void* p1, void* out, long n, double fract,
+                           void* stream) {
+    LB_REQUIRE(n > 0, "lb_lerp_f32: n");
+    hipLaunchKernelGGL(lerp_f32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)p0, (const float*)p1, (float*)out, n, (float)(1.0 - fract),
+                       (float)fract);
+    return lb_check_launch("lb_lerp_f32");
+}
+
+// ------------------------------------------------------------------------------------------
+// Scheduler kernels.  Per-sample parameters live in device memory so that a captured hipGraph
+// can be replayed with new sigmas / guidance without re-instantiation:
+//   params[b*8 + 0] sigma_from   [1] sigma_to (Euler) or sigma_down (ancestral)   [2] sigma_up
+//   params[b*8 + 3] guidance scale   [4] dt = fp32(sigma_next - sigma_from), computed in double
+//   on the host exactly like the Python-float arithmetic of the diffusers schedulers.
+// ------------------------------------------------------------------------------------------
+#define LB_STEP_STRIDE 8
+
+// x_in = half(x / sqrt(sigma^2 + 1)); with `dup` the batch is written twice (CFG: [uncond | cond]).
+__global__ void scale_input_kernel(const f16* __restrict__ x, f16* __restrict__ out,
+                                   const float* __restrict__ params, long per_sample, int batch,
+                                   int dup) {
+    const long total = per_sample * batch;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int b = (int)(i / per_sample);
+        const float s = params[b * LB_STEP_STRIDE + 0];
+        const float denom = sqrtf(s * s + 1.0f);
+        const f16 v = (f16)((float)x[i] / denom);
+        out[i] = v;
+        if (dup) out[i + total] = v;
+    }
+}
+
+extern "C" int lb_scale_model_input_f16(const void* x, void* out, const float* params_dev,
+                                        long per_sample, int batch, int dup_for_cfg, void* stream) {
+    LB_REQUIRE(per_sample > 0 && batch > 0, "lb_scale_model_input_f16: sizes");
+    hipLaunchKernelGGL(scale_input_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const f16*)x, (f16*)out, params_dev, per_sample, batch,
+                       dup_for_cfg);
+    return lb_check_launch("lb_scale_model_input_f16");
+}
+
+// eps layout: cfg == 0: eps[b] ; cfg == 1: eps[0..B) = uncond, eps[B..2B) = text.
+// CFG combine reproduces the fp16 tensor arithmetic of diffusers_holder.py:348-349
+// (sub, scalar mul, add — each rounded to fp16); the update itself is fp32, rounded once.
+__global__ void euler_step_kernel(const f16* __restrict__ x, const f16* __restrict__ eps,
+                                  const f16* __restrict__ noise, f16* __restrict__ out,
+                                  const float* __restrict__ params, long per_sample, int batch,
+                                  int cfg, int ancestral) {
+    const long total = per_sample * batch;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int b = (int)(i / per_sample);
+        const float s_from = params[b * LB_STEP_STRIDE + 0];
+        const float dt = params[b * LB_STEP_STRIDE + 4];
+        const float s_up = params[b * LB_STEP_STRIDE + 2];
+        const float g = params[b * LB_STEP_STRIDE + 3];
+        f16 e;
+        if (cfg) {
+            const f16 eu = eps[i], et = eps[i + total];
+            const f16 diff = (f16)((float)et - (float)eu);
+            const f16 sc = (f16)(g * (float)diff);
+            e = (f16)((float)eu + (float)sc);
+        } else {
+            e = eps[i];
+        }
+        const float xf = (float)x[i];
+        const float x0 = __fsub_rn(xf, __fmul_rn(s_from, (float)e));
+        const float d = __fdiv_rn(__fsub_rn(xf, x0), s_from);
+        float nxt = __fadd_rn(xf, __fmul_rn(d, dt));
+        if (ancestral) nxt = __fadd_rn(nxt, __fmul_rn((float)noise[i], s_up));
+        out[i] = (f16)nxt;
+    }
+}
+
+extern "C" int lb_euler_step_f16(const void* x, const void* eps, const void* noise, void* out,
+                                 const float* params_dev, long per_sample, int batch, int cfg,
+                                 int ancestral, void* stream) {
+    LB_REQUIRE(per_sample > 0 && batch > 0, "lb_euler_step_f16: sizes");
+    LB_REQUIRE(!ancestral || noise != nullptr, "lb_euler_step_f16: ancestral step needs noise");
+    hipLaunchKernelGGL(euler_step_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const f16*)x, (const f16*)eps, (const f16*)noise,
+                       (f16*)out, params_dev, per_sample, batch, cfg, ancestral);
+    return lb_check_launch("lb_euler_step_f16");
+}

@@ -1,0 +1,241 @@
+// GroupNorm(+SiLU) on NHWC activations and row LayerNorm for gfx950.
+//
+// GroupNorm is two launches with a deterministic reduction tree (no float atomics):
+//   1. gn_partial: grid (pixel chunks, B).  Every thread owns a FIXED 8-channel vector and walks
+//      the chunk's pixels with coalesced 16-B loads; per-channel sums meet in LDS and one thread
+//      per group folds them in float64 -> partial[b][chunk][group] = (sum, sumsq).
+//   2. gn_apply:   grid (blocks, B).  Prologue folds the chunk partials of its sample into
+//      mean / rstd (float64), then a coalesced normalise * gamma + beta (+SiLU) pass writes fp16.
+// Input may be fp16 (UNet) or fp32 (VAE residual stream).
+//
+// Replaces torch.nn.GroupNorm / LayerNorm inside diffusers' ResnetBlock2D, Transformer2DModel,
+// BasicTransformerBlock and the VAE decoder (reached from
+// /root/reference/latentblending/diffusers_holder.py:336 and :135).
+#include "lb_common.h"
+
+#define GN_MAX_GROUPS 32
+#define GN_MAX_CHUNKS 64
+
+template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_type(8))); };
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<f16>(const f16* p, float (&v)[8]) {
+    const f16x8 x = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+}
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+
+// x: [B][HW][ldx]; partial: [B][nchunk][groups][2] doubles
+template <typename T, int VPT>
+__global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ x,
+                                                         double* __restrict__ partial, int HW, int C,
+                                                         int ldx, int groups, int chunk_px) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];   // [2][rows][C]
+    const int vecs = C >> 3;
+    const int rows = VPT == 1 ? 256 / vecs : 1;
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, b = blockIdx.y, nchunk = gridDim.x;
+    const int px_begin = chunk * chunk_px;
+    int px_end = px_begin + chunk_px;
+    if (px_end > HW) px_end = HW;
+    const int r = VPT == 1 ? tid / vecs : 0;
+    const bool active = VPT == 1 ? tid < rows * vecs : true;
+    float* lsum = gn_lds;
+    float* lsq = gn_lds + rows * C;
+
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int v = VPT == 1 ? tid % vecs : tid + j * 256;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (active && v < vecs) {
+            const T* base = x + ((long)b * HW) * ldx + v * 8;
+            for (int px = px_begin + r; px < px_end; px += rows) {
+                float val[8];
+                load8<T>(base + (long)px * ldx, val);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[e] += val[e]; q[e] += val[e] * val[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                lsum[r * C + v * 8 + e] = s[e];
+                lsq[r * C + v * 8 + e] = q[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        double s = 0, q = 0;
+        for (int rr = 0; rr < rows; ++rr)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                s += (double)lsum[rr * C + c];
+                q += (double)lsq[rr * C + c];
+            }
+        double* out = partial + (((long)b * nchunk + chunk) * groups + tid) * 2;
+        out[0] = s;
+        out[1] = q;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
+                                                       const double* __restrict__ partial,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       f16* __restrict__ y, int HW, int C, int ldx,
+                                                       int ldy, int groups, int nchunk, float eps,
+                                                       int silu) {
+    __shared__ float mean_s[GN_MAX_GROUPS], rstd_s[GN_MAX_GROUPS];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups;
+    if (tid < groups) {
+        double s = 0, q = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const double* pp = partial + (((long)b * nchunk + c) * groups + tid) * 2;
+            s += pp[0];
+            q += pp[1];
+        }
+        const double cnt = (double)HW * cpg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0) var = 0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int vecs = C >> 3;
+    const long items = (long)HW * vecs;
+    for (long i = (long)blockIdx.x * 256 + tid; i < items; i += (long)gridDim.x * 256) {
+        const int px = (int)(i / vecs);
+        const int v = (int)(i - (long)px * vecs);
+        const int c0 = v * 8;
+        float val[8];
+        load8<T>(x + ((long)b * HW + px) * ldx + c0, val);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+        int grp = c0 / cpg;
+        int left = (grp + 1) * cpg - c0;
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (left == 0) { ++grp; left = cpg; }
+            --left;
+            const float ga = e < 4 ? g0[e & 3] : g1[e & 3];
+            const float be = e < 4 ? b0[e & 3] : b1[e & 3];
+            float t = (val[e] - mean_s[grp]) * rstd_s[grp] * ga + be;
+            if (silu) t = lb_silu(t);
+            o[e] = (f16)t;
+        }
+        *reinterpret_cast<f16x8*>(y + ((long)b * HW + px) * ldy + c0) = o;
+    }
+}
+
+extern "C" long lb_groupnorm_workspace_bytes(int B, int groups) {
+    return (long)B * GN_MAX_CHUNKS * groups * 2 * (long)sizeof(double);
+}
+
+// x: [B][HW][ldx] (fp16, or fp32 when x_is_f32), y: [B][HW][ldy] fp16, gamma/beta fp32 [C]
+extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta,
+                                 void* workspace, int B, int HW, int C, int ldx, int ldy, int groups,
+                                 float eps, int silu, int x_is_f32, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    LB_REQUIRE(B > 0 && HW > 0 && C > 0, "lb_groupnorm_nhwc: sizes");
+    LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "lb_groupnorm_nhwc: C/ld multiple of 8");
+    LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_nhwc: groups");
+    LB_REQUIRE(C <= 4096, "lb_groupnorm_nhwc: C <= 4096");
+    const int vecs = C / 8;
+    int chunk_px = (HW + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS;
+    if (chunk_px < 32) chunk_px = 32;
+    if (HW >= 4096 && chunk_px < 128) chunk_px = 128;
+    const int nchunk = (HW + chunk_px - 1) / chunk_px;
+    double* partial = (double*)workspace;
+    const int vpt = vecs <= 256 ? 1 : 2;
+    const int rows = vpt == 1 ? 256 / vecs : 1;
+    const size_t lds = (size_t)2 * rows * C * sizeof(float);
+    dim3 grid1(nchunk, B);
+#define GN_PART(T, V) hipLaunchKernelGGL((gn_partial_kernel<T, V>), grid1, dim3(256), lds, stream, \
+                                         (const T*)x, partial, HW, C, ldx, groups, chunk_px)
+    if (x_is_f32) { if (vpt == 1) GN_PART(float, 1); else GN_PART(float, 2); }
+    else          { if (vpt == 1) GN_PART(f16, 1);   else GN_PART(f16, 2); }
+#undef GN_PART
+    int rc = lb_check_launch("lb_groupnorm_nhwc(partial)");
+    if (rc) return rc;
+    long bx = ((long)HW * vecs + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    dim3 grid2((unsigned)bx, B);
+    if (x_is_f32)
+        hipLaunchKernelGGL((gn_apply_kernel<float>), grid2, dim3(256), 0, stream, (const float*)x,
+                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<f16>), grid2, dim3(256), 0, stream, (const f16*)x,
+                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu);
+    return lb_check_launch("lb_groupnorm_nhwc(apply)");
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension: one wave per row, row kept in registers (C <= 2048).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) layernorm_kernel(const f16* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        f16* __restrict__ y, int M, int C, int ldx,
+                                                        int ldy, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int vecs = C >> 3;
+    float val[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = lane + j * 64;
+        if (v < vecs) {
+            load8<f16>(x + (long)row * ldx + v * 8, val[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += val[j][e];
+        }
+    }
+    const float mean = lb_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = lane + j * 64;
+        if (v < vecs) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = val[j][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(lb_wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int v = lane + j * 64;
+        if (v < vecs) {
+            const int c0 = v * 8;
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = (f16)((val[j][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e]);
+            *reinterpret_cast<f16x8*>(y + (long)row * ldy + c0) = o;
+        }
+    }
+}
+
+extern "C" int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int M,
+                                int C, int ldx, int ldy, float eps, void* stream) {
+    LB_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "lb_layernorm_f16: C multiple of 8, <= 2048");
+    LB_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "lb_layernorm_f16: ld multiple of 8");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, gamma, beta, (f16*)y, M, C, ldx, ldy, eps);
+    return lb_check_launch("lb_layernorm_f16");
+}

@@ -1,0 +1,119 @@
+"""ctypes binding of ``liblbhip.so`` (contract: ``include/lb_hip.h``).
+
+The library is built in-tree by ``latentblending_amd/csrc/build.py`` (``__graft_entry__.build()``)
+and loaded AFTER ``import torch`` so that both share one HIP runtime.  There is no fallback: a
+missing library raises ``ImportError``; a failing launch raises ``RuntimeError`` with the
+library's own error string.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: shares libamdhip64 with the extension)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbhip.so")
+
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class LbGemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("rowvec", C.c_void_p), ("partial", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
+        ("ld_rowvec", C.c_int), ("rows_per_batch", C.c_int),
+        ("alpha", C.c_float), ("flags", C.c_int),
+        ("conv", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Cin", C.c_int),
+        ("Hout", C.c_int), ("Wout", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+        ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
+        ("splitk", C.c_int),
+    ]
+
+
+class LbAttnParams(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("Sq", C.c_int), ("Skv", C.c_int), ("Skv_valid", C.c_int),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
+GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU = 1, 2, 4, 8, 16, 32
+
+_vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+
+# name -> (restype, argtypes); launchers (restype int) are wrapped with error checking
+SIGNATURES = {
+    "lb_version": (_i, []),
+    "lb_last_error_string": (C.c_char_p, []),
+    "lb_device_info": (_i, [_i, C.POINTER(_i), C.POINTER(_l), C.c_char_p, _i]),
+    "lb_slerp_pairs_f16": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
+    "lb_slerp_pairs_f32": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
+    "lb_slerp_pairs_f64": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
+    "lb_slerp_batched_f16": (_i, [_vp, _vp, _vp, _vp, _l, _l, _vp]),
+    "lb_lerp_f16": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
+    "lb_lerp_f32": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
+    "lb_scale_model_input_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "lb_euler_step_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "lb_gemm_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
+    "lb_gemm_workspace_bytes": (_l, [_i, _i]),
+    "lb_gemm_set_tuning": (None, [_i, _i]),
+    "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
+    "lb_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "lb_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "lb_attn_fwd_d64": (_i, [C.POINTER(LbAttnParams), _vp]),
+    "lb_softmax_rows_f16": (_i, [_vp, _i, _i, _i, _f, _vp]),
+    "lb_sinusoid_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "lb_copy_cols_f16": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "lb_cast_f16_to_f32": (_i, [_vp, _vp, _l, _vp]),
+    "lb_cast_f32_to_f16": (_i, [_vp, _vp, _l, _vp]),
+    "lb_nchw_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "lb_nhwc_to_nchw_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "lb_postprocess_u8": (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    "lb_lpips_prep_u8": (_i, [_vp, _vp, _l, _vp]),
+    "lb_maxpool3s2_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "lb_lpips_tap": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "lb_fill_f32": (_i, [_vp, _l, _f, _vp]),
+}
+
+_NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
+             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning"}
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            f"latentblending_amd: {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback for the kernel path.")
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+_lib = _load()
+
+
+class _Api:
+    pass
+
+
+def _wrap(name, fn):
+    def checked(*args):
+        rc = fn(*args)
+        if rc != 0:
+            msg = _lib.lb_last_error_string()
+            raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")
+        return rc
+    checked.__name__ = name
+    return checked
+
+
+api = _Api()
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(_lib, _name)          # AttributeError here == header/library mismatch
+    _fn.restype = _res
+    _fn.argtypes = _args
+    setattr(api, _name, _fn if _name in _NO_CHECK else _wrap(_name, _fn))

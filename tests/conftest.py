@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def results_log():
+    """Parity metrics collected across GPU tests, dumped to gpurun_out/parity_metrics.json."""
+    import json
+    log = {}
+    yield log
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_metrics.json"), "w") as fh:
+        json.dump(log, fh, indent=1, sort_keys=True)

@@ -1,0 +1,426 @@
+"""Per-kernel parity on a real MI355X: every C-ABI launcher against the CPU oracle
+(oracle/sdxl_ref.py) or a plain PyTorch fp32 reference of the same op, on seeded inputs.
+
+Tolerances (stated per test): slerp / lerp / Euler <= 1 fp16 ulp (exact where the reference is
+exact); fp16 GEMM / conv / attention / norms: rel-L2 <= 2e-3 and max-abs <= 2^-8 * max|ref|
+(+ small absolute floor) against an fp32 reference evaluated on the same fp16-rounded inputs.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sdxl_ref as R  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def ops():
+    from latentblending_amd.hip import ops as o
+    return o
+
+
+def lib():
+    from latentblending_amd.hip import lib as l
+    return l
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def ulp_diff_f16(a, b):
+    ai = a.cpu().view(torch.int16).to(torch.int32)
+    bi = b.cpu().view(torch.int16).to(torch.int32)
+    ai = torch.where(ai < 0, -32768 - ai, ai)
+    bi = torch.where(bi < 0, -32768 - bi, bi)
+    return int((ai - bi).abs().max())
+
+
+def check_close(log, name, got, ref, rel=2e-3, frac=2 ** -8, floor=1e-3):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs().max().item()
+    rl2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    bound = frac * ref.abs().max().item() + floor
+    log[name] = {"max_abs": err, "rel_l2": rl2, "bound_abs": bound}
+    print(f"[parity] {name}: max_abs={err:.3e} (bound {bound:.3e}) rel_l2={rl2:.3e}")
+    assert rl2 <= rel, f"{name}: rel-L2 {rl2:.3e} > {rel}"
+    assert err <= bound, f"{name}: max-abs {err:.3e} > {bound:.3e}"
+
+
+# ------------------------------------------------------------------ mixing -------------------
+@pytest.mark.parametrize("n", [4096, 16384, 65536])
+def test_slerp_f16(n, results_log):
+    o = ops()
+    p0, p1 = rnd(1, 4, n // 4, seed=1, scale=3.0), rnd(1, 4, n // 4, seed=2, scale=3.0)
+    worst = 0
+    for f in [0.0, 0.25, 0.37, 0.5, 1.0]:
+        got = o.slerp(p0.to(DEV), p1.to(DEV), f)
+        ref = R.slerp(p0, p1, f)
+        assert got.dtype == torch.float16 and got.shape == p0.shape
+        d = ulp_diff_f16(got, ref)
+        worst = max(worst, d)
+        if f in (0.0, 1.0):
+            assert torch.equal(got.cpu(), p0 if f == 0.0 else p1), f"slerp f={f} must be exact"
+    results_log[f"slerp_f16_n{n}_max_ulp"] = worst
+    assert worst <= 1
+
+
+def test_slerp_edge_cases(results_log):
+    o = ops()
+    a = rnd(16384, seed=3)
+    same = o.slerp(a.to(DEV), a.to(DEV), 0.3)
+    assert ulp_diff_f16(same, R.slerp(a, a, 0.3)) <= 1
+    anti = o.slerp(a.to(DEV), (-a).to(DEV), 0.5).cpu()
+    ref = R.slerp(a, -a, 0.5)
+    assert torch.allclose(anti.float(), ref.float(), atol=1e-3)
+    z = torch.zeros(4096, dtype=torch.float16)
+    assert torch.isnan(o.slerp(z.to(DEV), a[:4096].to(DEV), 0.5)).all() == torch.isnan(R.slerp(z, a[:4096], 0.5)).all()
+    # fp32 / fp64 inputs come back as fp32 (reference utils.py:66-69)
+    for dt in (torch.float32, torch.float64):
+        x, y = rnd(1001, seed=4, dtype=dt), rnd(1001, seed=5, dtype=dt)
+        got = o.slerp(x.to(DEV), y.to(DEV), 0.41)
+        ref = R.slerp(x, y, 0.41)
+        assert got.dtype == torch.float32
+        assert torch.allclose(got.cpu(), ref, rtol=1e-6, atol=1e-6)
+    # odd length + misaligned views take the scalar path
+    x, y = rnd(4099, seed=6), rnd(4099, seed=7)
+    xd, yd = x.to(DEV), y.to(DEV)
+    assert ulp_diff_f16(o.slerp(xd[1:], yd[1:], 0.6), R.slerp(x[1:], y[1:], 0.6)) <= 1
+    # several pairs in one launch (more than the 16-pair kernarg block)
+    ps = [rnd(8192, seed=10 + i) for i in range(20)]
+    qs = [rnd(8192, seed=40 + i) for i in range(20)]
+    fr = [i / 19 for i in range(20)]
+    outs = o.slerp_pairs([p.to(DEV) for p in ps], [q.to(DEV) for q in qs], fr)
+    assert max(ulp_diff_f16(g, R.slerp(p, q, f)) for g, p, q, f in zip(outs, ps, qs, fr)) <= 1
+
+
+def test_slerp_batched(results_log):
+    o = ops()
+    for n in (16384, 65536, 131072):     # LDS-staged and re-read variants
+        p0, p1 = rnd(6, n, seed=8, scale=2.0), rnd(6, n, seed=9, scale=2.0)
+        fr = torch.tensor([0.0, 0.1, 0.5, 0.77, 1.0, 0.33], dtype=torch.float64)
+        got = o.slerp_batched(p0.to(DEV), p1.to(DEV), fr.to(DEV)).cpu()
+        for i in range(6):
+            assert ulp_diff_f16(got[i], R.slerp(p0[i], p1[i], float(fr[i]))) <= 1
+
+
+def test_lerp_bit_exact(results_log):
+    o = ops()
+    a, b = rnd(1, 77, 2048, seed=11), rnd(1, 77, 2048, seed=12)
+    for f in (0.0, 0.125, 0.5, 0.7321, 1.0):
+        got = o.lerp(a.to(DEV), b.to(DEV), f).cpu()
+        ref = R.lerp(a, b, f)
+        assert got.dtype == ref.dtype and torch.equal(got, ref), f"lerp f={f}"
+    a32, b32 = rnd(1, 1280, seed=13, dtype=torch.float32), rnd(1, 1280, seed=14, dtype=torch.float32)
+    assert torch.equal(o.lerp(a32.to(DEV), b32.to(DEV), 0.3).cpu(), R.lerp(a32, b32, 0.3))
+
+
+@pytest.mark.parametrize("ancestral", [True, False])
+def test_euler_step_matches_oracle(ancestral, results_log):
+    o = ops()
+    sched = R.EulerScheduler(ancestral=ancestral)
+    sched.set_timesteps(4 if ancestral else 30)
+    x = rnd(2, 4, 64, 64, seed=15, scale=5.0)
+    eps = rnd(2, 4, 64, 64, seed=16)
+    noise = rnd(2, 4, 64, 64, seed=17)
+    sched.noise_source = lambda shape: noise[:1]
+    worst = 0
+    for i in range(len(sched.timesteps) - (0 if not ancestral else 0)):
+        t = sched.timesteps[i]
+        sched._step_index = None
+        scaled_ref = sched.scale_model_input(x[:1], t)
+        sched._step_index = None
+        ref = sched.step(eps[:1], t, x[:1])[0]
+        s_from, s_to = float(sched.sigmas[i]), float(sched.sigmas[i + 1])
+        if ancestral:
+            s_up, s_down = R.ancestral_sigmas(s_from, s_to)
+            row = (s_from, s_down, s_up, 0.0, s_down - s_from)
+        else:
+            row = (s_from, s_to, 0.0, 0.0, s_to - s_from)
+        params = o.step_params([row, row], DEV)
+        got_scaled = o.scale_model_input(x.to(DEV), params)
+        assert ulp_diff_f16(got_scaled[:1], scaled_ref) <= 1
+        got = o.euler_step(x.to(DEV), eps.to(DEV), params, noise=noise[:1].expand(2, -1, -1, -1).contiguous().to(DEV),
+                           ancestral=ancestral)
+        worst = max(worst, ulp_diff_f16(got[:1], ref))
+    results_log[f"euler_{'anc' if ancestral else 'plain'}_max_ulp"] = worst
+    assert worst <= 1
+
+
+def test_euler_cfg_combine(results_log):
+    o = ops()
+    x = rnd(1, 4, 32, 32, seed=18, scale=4.0)
+    eu, et = rnd(1, 4, 32, 32, seed=19), rnd(1, 4, 32, 32, seed=20)
+    g, s_from, s_to = 3.5, 2.0, 1.5
+    eps = eu + g * (et - eu)                       # fp16 tensor arithmetic, as diffusers_holder.py:349
+    sched_x = x.float()
+    x0 = sched_x - s_from * eps.float()
+    ref = (sched_x + ((sched_x - x0) / s_from) * (s_to - s_from)).half()
+    params = o.step_params([(s_from, s_to, 0.0, g, s_to - s_from)], DEV)
+    got = o.euler_step(x.to(DEV), torch.cat([eu, et]).to(DEV), params, cfg=True)
+    assert ulp_diff_f16(got, ref) <= 1
+    dup = o.scale_model_input(x.to(DEV), params, dup_for_cfg=True)
+    assert dup.shape[0] == 2 and torch.equal(dup[0], dup[1])
+
+
+# ------------------------------------------------------------------ GEMM ---------------------
+GEMM_SHAPES = [(256, 1280, 1280), (1024, 3840, 640), (100, 64, 72), (4096, 320, 2880), (77, 1280, 2048),
+               (2, 1280, 320), (333, 132, 200)]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_gemm_plain(shape, tile, results_log):
+    o, l = ops(), lib()
+    M, N, K = shape
+    A, W = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5)
+    bias = rnd(N, seed=23, dtype=torch.float32)
+    res = rnd(M, N, seed=24)
+    ref = A.float() @ W.float().t() + bias + res.float()
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    check_close(results_log, f"gemm_{M}x{N}x{K}_tile{tile}", got, ref)
+
+
+def test_gemm_transpose_detecting(results_log):
+    """A = I with an asymmetric W: a swapped fragment layout cannot pass."""
+    o = ops()
+    n = 128
+    A = torch.eye(n, dtype=torch.float16)
+    W = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 / 251).half()
+    got = o.gemm(A.to(DEV), W.to(DEV))
+    assert torch.equal(got.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("splitk", [2, 5, 16])
+def test_gemm_splitk(splitk, results_log):
+    o, l = ops(), lib()
+    M, N, K = 256, 1280, 5120
+    A, W = rnd(M, K, seed=25), rnd(N, K, seed=26, scale=K ** -0.5)
+    bias, res = rnd(N, seed=27, dtype=torch.float32), rnd(M, N, seed=28)
+    ref = A.float() @ W.float().t() + bias + res.float()
+    l.api.lb_gemm_set_tuning(3, splitk)
+    try:
+        got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    check_close(results_log, f"gemm_splitk{splitk}", got, ref)
+    got_auto = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+    check_close(results_log, "gemm_splitk_auto", got_auto, ref)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_geglu(tile, results_log):
+    o, l = ops(), lib()
+    M, C = 300, 640
+    A = rnd(M, C, seed=29)
+    W = rnd(8 * C, C, seed=30, scale=C ** -0.5)
+    bias = rnd(8 * C, seed=31, dtype=torch.float32, scale=0.1)
+    proj = A.float() @ W.float().t() + bias
+    h, gate = proj.chunk(2, dim=-1)
+    ref = h * F.gelu(gate)
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_GEGLU)
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    assert got.shape == (M, 4 * C)
+    check_close(results_log, f"gemm_geglu_tile{tile}", got, ref)
+
+
+def test_gemm_epilogues(results_log):
+    o, l = ops(), lib()
+    M, N, K = 512, 256, 320
+    A, W = rnd(M, K, seed=32), rnd(N, K, seed=33, scale=K ** -0.5)
+    bias = rnd(N, seed=34, dtype=torch.float32)
+    base = A.float() @ W.float().t()
+    # transposed store
+    got = o.gemm(A.to(DEV), W.to(DEV), flags=l.GEMM_TRANS_OUT)
+    check_close(results_log, "gemm_trans_out", got, base.t())
+    # fp32 output with fp32 residual, alpha
+    res32 = rnd(M, N, seed=35, dtype=torch.float32, scale=100.0)
+    got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), residual=res32.to(DEV), alpha=0.5,
+                 flags=l.GEMM_OUT_F32 | l.GEMM_RES_F32)
+    assert got.dtype == torch.float32
+    check_close(results_log, "gemm_f32_out", got, 0.5 * base + bias + res32, rel=1e-4, frac=2 ** -12)
+    # per-sample row vector (time-embedding add): 4 samples x 128 rows
+    rv = rnd(4, N, seed=36)
+    got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), rowvec=rv.to(DEV), rows_per_batch=128)
+    check_close(results_log, "gemm_rowvec", got, base + bias + rv.float().repeat_interleave(128, 0))
+    # activations
+    got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_SILU)
+    check_close(results_log, "gemm_silu", got, F.silu(base + bias))
+    got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_RELU)
+    check_close(results_log, "gemm_relu", got, F.relu(base + bias))
+
+
+# ------------------------------------------------------------------ conv ---------------------
+CONV_CASES = [
+    # (B, H, W, Cin, Cout, k, stride, pad, ups)
+    (2, 16, 16, 64, 128, 3, 1, 1, 0),
+    (1, 32, 32, 320, 320, 3, 1, 1, 0),
+    (2, 16, 16, 64, 64, 3, 2, 1, 0),      # UNet downsampler
+    (1, 8, 8, 128, 128, 3, 1, 1, 1),      # fused nearest-2x upsample + conv
+    (2, 16, 16, 4, 64, 3, 1, 1, 0),       # conv_in: Cin 4 padded to 8
+    (1, 16, 16, 192, 64, 1, 1, 0, 0),     # 1x1 shortcut
+    (1, 16, 16, 320, 4, 3, 1, 1, 0),      # conv_out: tiny N
+    (1, 64, 64, 3, 64, 11, 4, 2, 0),      # LPIPS conv1
+    (1, 15, 15, 64, 192, 5, 1, 2, 0),     # LPIPS conv2
+    (1, 10, 14, 72, 96, 3, 1, 1, 0),      # non-square, Cin not a multiple of 64
+]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 3])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_implicit_gemm(case, tile, results_log):
+    o, l = ops(), lib()
+    B, H, Wd, Cin, Cout, k, st, pad, ups = case
+    x = rnd(B, Cin, H, Wd, seed=37)
+    w = rnd(Cout, Cin, k, k, seed=38, scale=(Cin * k * k) ** -0.5)
+    bias = rnd(Cout, seed=39, dtype=torch.float32)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), bias, stride=st, padding=pad).permute(0, 2, 3, 1)
+    cin_p = (Cin + 7) // 8 * 8
+    cout_p = (Cout + 3) // 4 * 4
+    x_nhwc = torch.zeros(B, H, Wd, cin_p, dtype=torch.float16)
+    x_nhwc[..., :Cin] = x.permute(0, 2, 3, 1)
+    wp = torch.zeros(cout_p, k * k * cin_p, dtype=torch.float16)
+    wp[:Cout] = o.pack_conv_weight(w, cin_p)
+    bp = torch.zeros(cout_p, dtype=torch.float32)
+    bp[:Cout] = bias
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        got = o.gemm(x_nhwc.to(DEV), wp.to(DEV), bias=bp.to(DEV),
+                     conv=dict(KH=k, KW=k, stride=st, pad=pad, ups=ups))
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    check_close(results_log, f"conv_{'_'.join(map(str, case))}_tile{tile}", got[..., :Cout], ref)
+
+
+def test_conv_resnet_epilogue(results_log):
+    """conv + bias + per-sample time-embedding vector + residual, the ResnetBlock2D epilogue."""
+    o = ops()
+    B, H, Wd, C = 2, 16, 16, 128
+    x, w = rnd(B, C, H, Wd, seed=40), rnd(C, C, 3, 3, seed=41, scale=(9 * C) ** -0.5)
+    bias, temb, res = rnd(C, seed=42, dtype=torch.float32), rnd(B, C, seed=43), rnd(B, H, Wd, C, seed=44)
+    ref = (F.conv2d(x.float(), w.float(), bias, padding=1) + temb.float()[:, :, None, None]).permute(0, 2, 3, 1) + res.float()
+    got = o.gemm(x.permute(0, 2, 3, 1).contiguous().to(DEV), o.pack_conv_weight(w).to(DEV), bias=bias.to(DEV),
+                 rowvec=temb.to(DEV), rows_per_batch=H * Wd, residual=res.to(DEV),
+                 conv=dict(KH=3, KW=3, stride=1, pad=1))
+    check_close(results_log, "conv_resnet_epilogue", got, ref)
+
+
+# ------------------------------------------------------------------ norms --------------------
+@pytest.mark.parametrize("case", [(1, 4096, 320, False), (2, 256, 2560, False), (1, 1024, 1920, False),
+                                  (1, 16384, 128, True), (2, 64, 32, False), (1, 4096, 512, True)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm(case, silu, results_log):
+    o = ops()
+    B, HW, C, f32_in = case
+    x = rnd(B, HW, C, seed=45, scale=2.0, dtype=torch.float32 if f32_in else torch.float16)
+    x = x + 0.5
+    gamma, beta = rnd(C, seed=46, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=47, dtype=torch.float32) * 0.1
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    got = o.groupnorm_nhwc(x.to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu)
+    check_close(results_log, f"groupnorm_{B}_{HW}_{C}_{int(f32_in)}_{int(silu)}", got, ref, floor=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(1024, 640), (256, 1280), (77, 2048), (5, 64)])
+def test_layernorm(shape, results_log):
+    o = ops()
+    M, C = shape
+    x = rnd(M, C, seed=48, scale=3.0) + 1
+    gamma, beta = rnd(C, seed=49, dtype=torch.float32) * 0.1 + 1, rnd(C, seed=50, dtype=torch.float32) * 0.1
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    got = o.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    check_close(results_log, f"layernorm_{M}_{C}", got, ref, floor=2e-3)
+
+
+# ------------------------------------------------------------------ attention ----------------
+@pytest.mark.parametrize("case", [(1, 10, 1024, 1024, 1024), (2, 20, 256, 256, 256), (2, 5, 100, 80, 77),
+                                  (1, 2, 64, 64, 64), (1, 10, 4096, 80, 77), (3, 4, 200, 200, 200)])
+def test_attention_d64(case, results_log):
+    o = ops()
+    B, H, Sq, Skv, valid = case
+    C = H * 64
+    q, k, v = rnd(B, Sq, C, seed=51), rnd(B, Skv, C, seed=52), rnd(B, Skv, C, seed=53)
+    ref = R.attention(q.float(), k.float()[:, :valid], v.float()[:, :valid], H)
+    vt = v.reshape(B * Skv, C).t().contiguous()                    # [C, B*Skv]
+    got = o.attention_d64(q.reshape(B * Sq, C).to(DEV), k.reshape(B * Skv, C).to(DEV), vt.to(DEV), B, H, Sq, Skv, valid)
+    check_close(results_log, f"attn_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
+
+
+def test_attention_spiked_scores(results_log):
+    """Force large running-max jumps between KV tiles (online-softmax rescale path)."""
+    o = ops()
+    B, H, S = 1, 2, 256
+    C = H * 64
+    q, k, v = rnd(B, S, C, seed=54), rnd(B, S, C, seed=55), rnd(B, S, C, seed=56)
+    k[0, 200] = q[0, 3] * 6.0          # one key far above the rest, in the last tile
+    k[0, 70] = q[0, 100] * 4.0
+    ref = R.attention(q.float(), k.float(), v.float(), H)
+    got = o.attention_d64(q.reshape(S, C).to(DEV), k.reshape(S, C).to(DEV), v.reshape(S, C).t().contiguous().to(DEV),
+                          B, H, S, S)
+    check_close(results_log, "attn_spiked", got.reshape(B, S, C), ref, floor=2e-3)
+
+
+def test_softmax_rows(results_log):
+    o = ops()
+    x = rnd(300, 4096, seed=57, scale=4.0)
+    ref = torch.softmax(x.float() * 0.3, dim=-1)
+    got = o.softmax_rows_(x.to(DEV).clone(), 0.3)
+    check_close(results_log, "softmax_rows", got, ref, floor=1e-4)
+
+
+# ------------------------------------------------------------------ small kernels ------------
+def test_small_kernels(results_log):
+    o = ops()
+    # sinusoid == oracle Timesteps
+    vals = torch.tensor([[999.0], [249.0], [1.0]])
+    ref = R.sinusoid(vals.reshape(-1), 320)
+    got = o.sinusoid(vals.to(DEV), 320)
+    check_close(results_log, "sinusoid_t", got, ref, floor=2e-3)
+    ids = torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]] * 2)
+    ref = R.sinusoid(ids.reshape(-1), 256).reshape(2, -1)
+    out = torch.zeros(2, 1280 + 6 * 256, dtype=torch.float16, device=DEV)
+    o.sinusoid(ids.to(DEV), 256, out=out, col_off=1280)
+    check_close(results_log, "sinusoid_ids", out[:, 1280:], ref, floor=2e-3)
+    assert (out[:, :1280] == 0).all()
+    # concat copy
+    a, b = rnd(50, 64, seed=58), rnd(50, 32, seed=59)
+    dst = torch.zeros(50, 96, dtype=torch.float16, device=DEV)
+    o.copy_cols(a.to(DEV), dst, 0)
+    o.copy_cols(b.to(DEV), dst, 64)
+    assert torch.equal(dst.cpu(), torch.cat([a, b], dim=1))
+    # layout converts
+    z = rnd(2, 4, 8, 8, seed=60)
+    nh = o.nchw_to_nhwc(z.to(DEV), 8, mul=1 / 0.13025)
+    ref = (z.float() / 0.13025)
+    check_close(results_log, "nchw_to_nhwc", nh[..., :4].permute(0, 3, 1, 2), ref)
+    assert (nh[..., 4:] == 0).all()
+    assert torch.equal(o.nhwc_to_nchw(o.nchw_to_nhwc(z.to(DEV), 8), 4).cpu(), z)
+    # uint8 quantisation == VaeImageProcessor.postprocess
+    img = rnd(1, 3, 16, 16, seed=61, dtype=torch.float32)
+    x4 = torch.zeros(1, 16, 16, 4)
+    x4[..., :3] = img.permute(0, 2, 3, 1)
+    got = o.postprocess_u8(x4.to(DEV)).cpu().numpy()
+    assert np.array_equal(got, R.postprocess_u8(img))
+    # max-pool
+    f = rnd(2, 64, 15, 15, seed=62)
+    ref = F.max_pool2d(f.float(), 3, 2).permute(0, 2, 3, 1)
+    got = o.maxpool3s2(f.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert torch.equal(got.cpu().float(), ref)
