@@ -130,7 +130,7 @@ int lb_sinusoid_f16(const float* vals_dev, int rows, int per_row, int val_stride
 int lb_copy_cols_f16(const void* src, void* dst, long rows, int cols, int ld_src, int ld_dst,
                      int dst_off, void* stream);
 int lb_cast_f16_to_f32(const void* x, void* y, long n, void* stream);
-int lb_cast_f32_to_f16(const void* x, void* y, long n, void* stream);
+int lb_cast_f32_to_f16(const void* x, void* y, long n, float mul, void* stream);
 int lb_nchw_to_nhwc_f16(const void* x, void* y, int B, int C, int HW, int ld, float mul, void* stream);
 int lb_nhwc_to_nchw_f16(const void* x, void* y, int B, int C, int HW, int ld, void* stream);
 /* VaeImageProcessor.postprocess (diffusers_holder.py:141): uint8 HWC frames on device */
@@ -138,9 +138,26 @@ int lb_postprocess_u8(const void* x, void* out_u8, long pixels, int ld, int x_is
 /* lpips.LPIPS(net='alex') pieces (blending_engine.py:744-758) */
 int lb_lpips_prep_u8(const void* img_u8, void* out_f16, long pixels, void* stream);
 int lb_maxpool3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, void* stream);
-int lb_lpips_tap(const void* feats, const float* lin, const int* pairs_dev, float* acc,
+/* feats_a / feats_b: HOST arrays of npairs (<= 16) device pointers to [HW][C] fp16 features;
+ * acc[pair] += tap distance; workspace: 16*128 floats */
+int lb_lpips_tap(const void* const* feats_a, const void* const* feats_b, const float* lin, float* acc,
                  float* workspace, int npairs, int HW, int C, void* stream);
 int lb_fill_f32(void* x, long n, float v, void* stream);
+int lb_copy_d2d(void* dst, const void* src, long bytes, void* stream);
+
+/* ---- launch programs (the MI355X-native stand-in for the reference's optional stable-fast
+ *      compile, blending_engine.py:88-96): record the launchers above once, replay them from
+ *      C++ or as one hipGraph ------------------------------------------------------------ */
+void* lb_program_create(void);
+void lb_program_destroy(void* prog);
+int lb_program_begin_record(void* prog);   /* launchers called on this thread are recorded, not run */
+int lb_program_end_record(void* prog);
+int lb_program_num_ops(void* prog);
+const char* lb_program_op_name(void* prog, int i);
+int lb_program_run(void* prog, void* stream);                        /* eager replay */
+int lb_program_run_range(void* prog, int begin, int end, void* stream);
+int lb_program_instantiate(void* prog);                              /* capture into a hipGraph */
+int lb_program_launch(void* prog, void* stream);                     /* graph launch (or eager) */
 
 #ifdef __cplusplus
 }

@@ -166,13 +166,12 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
 }
 
 extern "C" int lb_attn_fwd_d64(const LbAttnParams* pp, void* stream) {
-    const LbAttnParams& p = *pp;
+    const LbAttnParams p = *pp;
     LB_REQUIRE(p.B > 0 && p.H > 0 && p.Sq > 0 && p.Skv > 0, "lb_attn_fwd_d64: sizes");
     LB_REQUIRE(p.Skv % 8 == 0 && p.Skv_valid > 0 && p.Skv_valid <= p.Skv, "lb_attn_fwd_d64: Skv % 8, valid");
     LB_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldvt % 8 == 0 && p.ldo % 4 == 0, "lb_attn_fwd_d64: ld alignment");
     dim3 grid((p.Sq + 63) / 64, p.H, p.B);
-    hipLaunchKernelGGL(attn_fwd_d64_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
-    return lb_check_launch("lb_attn_fwd_d64");
+    LB_DISPATCH_STMT("lb_attn_fwd_d64", hipLaunchKernelGGL(attn_fwd_d64_kernel, grid, dim3(256), 0, s, p));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -214,6 +213,5 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(f16* __restrict__ x, 
 
 extern "C" int lb_softmax_rows_f16(void* x, int M, int N, int ld, float scale, void* stream) {
     LB_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "lb_softmax_rows_f16: N, ld multiples of 8");
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (f16*)x, N, ld, scale);
-    return lb_check_launch("lb_softmax_rows_f16");
+    LB_DISPATCH_STMT("lb_softmax_rows_f16", hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, s, (f16*)x, N, ld, scale));
 }

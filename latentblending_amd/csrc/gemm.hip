@@ -286,9 +286,24 @@ extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     return (long)16 * M * N * (long)sizeof(float);
 }
 
-extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream_) {
+static int gemm_launch_impl(LbGemmParams p, int tile, dim3 grid, hipStream_t stream) {
+    if (tile == 1) launch_variant<128, 128>(p, grid, stream);
+    else if (tile == 2) launch_variant<128, 64>(p, grid, stream);
+    else launch_variant<64, 64>(p, grid, stream);
+    int rc = lb_check_launch("lb_gemm_f16");
+    if (rc) return rc;
+    if (p.splitk > 1) {
+        const long quads = (long)p.M * (p.N / 4);
+        long gsz = (quads + 255) / 256;
+        if (gsz > 2048) gsz = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, stream, p);
+        rc = lb_check_launch("lb_gemm_f16(split-K reduce)");
+    }
+    return rc;
+}
+
+extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     LbGemmParams p = *pp;
-    hipStream_t stream = (hipStream_t)stream_;
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
     LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_gemm_f16: empty problem");
     LB_REQUIRE(p.K % 8 == 0 && p.ldw % 8 == 0, "lb_gemm_f16: K and ldw must be multiples of 8");
@@ -333,18 +348,6 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream_) {
     }
     p.splitk = splitk;
 
-    dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
-    if (tile == 1) launch_variant<128, 128>(p, grid, stream);
-    else if (tile == 2) launch_variant<128, 64>(p, grid, stream);
-    else launch_variant<64, 64>(p, grid, stream);
-    int rc = lb_check_launch("lb_gemm_f16");
-    if (rc) return rc;
-    if (splitk > 1) {
-        const long quads = (long)p.M * (p.N / 4);
-        long gsz = (quads + 255) / 256;
-        if (gsz > 2048) gsz = 2048;
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)gsz), dim3(256), 0, stream, p);
-        rc = lb_check_launch("lb_gemm_f16(split-K reduce)");
-    }
-    return rc;
+    const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
+    LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, grid, s));
 }

@@ -16,6 +16,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 extern "C" const char* lb_last_error_string(void);
 void lb_set_error(const char* what, hipError_t e);
 
+// ---- launch recording (program.hip) --------------------------------------------------------
+#ifdef __cplusplus
+#include <functional>
+bool lb_recording();
+void lb_record(const char* name, std::function<int(hipStream_t)> fn);
+// Body of every extern "C" launcher: record a closure while a program is recording, otherwise
+// launch on the caller's stream.  CALL is an expression using `s` (hipStream_t); everything it
+// names is captured BY VALUE, so pointer-to-host arguments must be copied into locals first.
+#define LB_DISPATCH(NAME, CALL)                                                   \
+    do {                                                                          \
+        if (lb_recording()) {                                                     \
+            lb_record(NAME, [=](hipStream_t s) -> int { return CALL; });          \
+            return 0;                                                             \
+        }                                                                         \
+        hipStream_t s = (hipStream_t)stream;                                      \
+        return CALL;                                                              \
+    } while (0)
+// Statement form: STMT is a kernel-launch statement using `s`; the launch status is returned.
+#define LB_DISPATCH_STMT(NAME, STMT) \
+    LB_DISPATCH(NAME, ([&]() -> int { STMT; return lb_check_launch(NAME); })())
+#endif
+
 static inline int lb_check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) lb_set_error(what, e);

@@ -35,10 +35,9 @@ __global__ void sinusoid_kernel(const float* __restrict__ vals, int rows, int pe
 extern "C" int lb_sinusoid_f16(const float* vals_dev, int rows, int per_row, int val_stride, int dim,
                                void* out, int ld_out, int col_off, void* stream) {
     LB_REQUIRE(rows > 0 && per_row > 0 && dim > 0 && dim % 2 == 0, "lb_sinusoid_f16: sizes");
-    hipLaunchKernelGGL(sinusoid_kernel, dim3(grid_for((long)rows * per_row * dim)), dim3(256), 0,
-                       (hipStream_t)stream, vals_dev, rows, per_row, dim, (f16*)out, ld_out, col_off,
-                       val_stride);
-    return lb_check_launch("lb_sinusoid_f16");
+    LB_DISPATCH_STMT("lb_sinusoid_f16", hipLaunchKernelGGL(sinusoid_kernel, dim3(grid_for((long)rows * per_row * dim)), dim3(256), 0,
+                       s, vals_dev, rows, per_row, dim, (f16*)out, ld_out, col_off,
+                       val_stride));
 }
 
 // dst[r][dst_off + c] = src[r][c], c < cols (multiple of 8), 16-B vectors
@@ -58,24 +57,25 @@ extern "C" int lb_copy_cols_f16(const void* src, void* dst, long rows, int cols,
                                 int dst_off, void* stream) {
     LB_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && dst_off % 8 == 0,
                "lb_copy_cols_f16: cols / ld / offset multiples of 8");
-    hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)src, (f16*)dst, rows, cols, ld_src, ld_dst, dst_off);
-    return lb_check_launch("lb_copy_cols_f16");
+    LB_DISPATCH_STMT("lb_copy_cols_f16", hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, s,
+                       (const f16*)src, (f16*)dst, rows, cols, ld_src, ld_dst, dst_off));
 }
 
 __global__ void cast_f16_f32_kernel(const f16* __restrict__ x, float* __restrict__ y, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (float)x[i];
 }
-__global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (f16)x[i];
+__global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, long n, float mul) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = (f16)fminf(fmaxf(x[i] * mul, -65504.f), 65504.f);
 }
 extern "C" int lb_cast_f16_to_f32(const void* x, void* y, long n, void* stream) {
-    hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (float*)y, n);
-    return lb_check_launch("lb_cast_f16_to_f32");
+    LB_DISPATCH_STMT("lb_cast_f16_to_f32", hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, (const f16*)x, (float*)y, n));
 }
-extern "C" int lb_cast_f32_to_f16(const void* x, void* y, long n, void* stream) {
-    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (f16*)y, n);
-    return lb_check_launch("lb_cast_f32_to_f16");
+// y = fp16(saturate(x * mul)); mul = 0 is read as 1 (a power-of-two down-scale keeps the VAE's
+// fp32 residual stream inside fp16 range for the next conv, whose epilogue multiplies back)
+extern "C" int lb_cast_f32_to_f16(const void* x, void* y, long n, float mul, void* stream) {
+    const float m = mul == 0.f ? 1.f : mul;
+    LB_DISPATCH_STMT("lb_cast_f32_to_f16", hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(grid_for(n)), dim3(256), 0, s, (const float*)x, (f16*)y, n, m));
 }
 
 // NCHW fp16 latent [B][C][HW] <-> NHWC fp16 [B][HW][ld] (C small: 4), with an optional scalar
@@ -101,15 +101,13 @@ __global__ void nhwc_to_nchw_kernel(const f16* __restrict__ x, f16* __restrict__
 }
 extern "C" int lb_nchw_to_nhwc_f16(const void* x, void* y, int B, int C, int HW, int ld, float mul, void* stream) {
     LB_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C, "lb_nchw_to_nhwc_f16: sizes");
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)B * HW * ld)), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, (f16*)y, B, C, HW, ld, mul == 0.f ? 1.f : mul);
-    return lb_check_launch("lb_nchw_to_nhwc_f16");
+    LB_DISPATCH_STMT("lb_nchw_to_nhwc_f16", hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)B * HW * ld)), dim3(256), 0, s,
+                       (const f16*)x, (f16*)y, B, C, HW, ld, mul == 0.f ? 1.f : mul));
 }
 extern "C" int lb_nhwc_to_nchw_f16(const void* x, void* y, int B, int C, int HW, int ld, void* stream) {
     LB_REQUIRE(B > 0 && C > 0 && HW > 0 && ld >= C, "lb_nhwc_to_nchw_f16: sizes");
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)B * C * HW)), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, (f16*)y, B, C, HW, ld);
-    return lb_check_launch("lb_nhwc_to_nchw_f16");
+    LB_DISPATCH_STMT("lb_nhwc_to_nchw_f16", hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)B * C * HW)), dim3(256), 0, s,
+                       (const f16*)x, (f16*)y, B, C, HW, ld));
 }
 
 // VAE output [B][HW][ld] (fp32 or fp16, channels 0..2) -> uint8 [B][HW][3]:
@@ -124,15 +122,18 @@ __global__ void postprocess_u8_kernel(const T* __restrict__ x, uint8_t* __restri
         out[i] = (uint8_t)rintf(v * 255.f);
     }
 }
-extern "C" int lb_postprocess_u8(const void* x, void* out_u8, long pixels, int ld, int x_is_f32, void* stream) {
-    LB_REQUIRE(pixels > 0 && ld >= 3, "lb_postprocess_u8: sizes");
+static int postprocess_impl(const void* x, void* out_u8, long pixels, int ld, int x_is_f32, hipStream_t s) {
     if (x_is_f32)
-        hipLaunchKernelGGL((postprocess_u8_kernel<float>), dim3(grid_for(pixels * 3)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((postprocess_u8_kernel<float>), dim3(grid_for(pixels * 3)), dim3(256), 0, s,
                            (const float*)x, (uint8_t*)out_u8, pixels, ld);
     else
-        hipLaunchKernelGGL((postprocess_u8_kernel<f16>), dim3(grid_for(pixels * 3)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((postprocess_u8_kernel<f16>), dim3(grid_for(pixels * 3)), dim3(256), 0, s,
                            (const f16*)x, (uint8_t*)out_u8, pixels, ld);
     return lb_check_launch("lb_postprocess_u8");
+}
+extern "C" int lb_postprocess_u8(const void* x, void* out_u8, long pixels, int ld, int x_is_f32, void* stream) {
+    LB_REQUIRE(pixels > 0 && ld >= 3, "lb_postprocess_u8: sizes");
+    LB_DISPATCH("lb_postprocess_u8", postprocess_impl(x, out_u8, pixels, ld, x_is_f32, s));
 }
 
 // ---- LPIPS helpers ------------------------------------------------------------------------
@@ -150,9 +151,8 @@ __global__ void lpips_prep_kernel(const uint8_t* __restrict__ img, f16* __restri
     }
 }
 extern "C" int lb_lpips_prep_u8(const void* img_u8, void* out_f16, long pixels, void* stream) {
-    hipLaunchKernelGGL(lpips_prep_kernel, dim3(grid_for(pixels)), dim3(256), 0, (hipStream_t)stream,
-                       (const uint8_t*)img_u8, (f16*)out_f16, pixels);
-    return lb_check_launch("lb_lpips_prep_u8");
+    LB_DISPATCH_STMT("lb_lpips_prep_u8", hipLaunchKernelGGL(lpips_prep_kernel, dim3(grid_for(pixels)), dim3(256), 0, s,
+                       (const uint8_t*)img_u8, (f16*)out_f16, pixels));
 }
 
 // NHWC max-pool k3 s2 (no padding): [N][H][W][C] -> [N][Ho][Wo][C], Ho = (H-3)/2+1
@@ -181,22 +181,23 @@ __global__ void maxpool3s2_kernel(const f16* __restrict__ x, f16* __restrict__ y
 extern "C" int lb_maxpool3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, void* stream) {
     LB_REQUIRE(N > 0 && H >= 3 && W >= 3 && C % 8 == 0, "lb_maxpool3s2_nhwc_f16: sizes");
     const int Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for((long)N * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo);
-    return lb_check_launch("lb_maxpool3s2_nhwc_f16");
+    LB_DISPATCH_STMT("lb_maxpool3s2_nhwc_f16", hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for((long)N * Ho * Wo * (C / 8))), dim3(256), 0, s,
+                       (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo));
 }
 
-// One LPIPS tap: feats [N][HW][C]; for every pair (ia, ib):
-//   d = mean_px sum_c lin[c] * (fa/(|fa|+eps) - fb/(|fb|+eps))^2
-// One wave per pixel; per-block partial sums are folded by a single thread in fixed order
-// (deterministic).  acc[pair] += d  (acc is zeroed by the caller before the first tap).
-__global__ void __launch_bounds__(256) lpips_tap_kernel(const f16* __restrict__ feats, const float* __restrict__ lin,
-                                                        const int* __restrict__ pairs, float* __restrict__ block_part,
-                                                        int HW, int C) {
+// One LPIPS tap for up to 16 frame pairs: features fa/fb [HW][C] per pair (pointers by value);
+//   d = mean_px sum_c lin[c] * (fa/(|fa|+eps) - fb/(|fb|+eps))^2 ;  acc[pair] += d
+// One wave per pixel; per-block partial sums are folded by one thread in fixed order
+// (deterministic, no float atomics).  acc must be zeroed before the first tap.
+#define LPIPS_MAX_PAIRS 16
+struct LpipsPairs { const f16* a[LPIPS_MAX_PAIRS]; const f16* b[LPIPS_MAX_PAIRS]; };
+
+__global__ void __launch_bounds__(256) lpips_tap_kernel(LpipsPairs pp, const float* __restrict__ lin,
+                                                        float* __restrict__ block_part, int HW, int C) {
     __shared__ float red[4];
     const int pair = blockIdx.y;
-    const f16* fa = feats + (long)pairs[pair * 2 + 0] * HW * C;
-    const f16* fb = feats + (long)pairs[pair * 2 + 1] * HW * C;
+    const f16* fa = pp.a[pair];
+    const f16* fb = pp.b[pair];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
     for (int px = blockIdx.x * 4 + wave; px < HW; px += gridDim.x * 4) {
@@ -226,17 +227,23 @@ __global__ void lpips_fold_kernel(const float* __restrict__ block_part, float* _
         acc[pair] += (float)(s * inv_hw);
     }
 }
-extern "C" int lb_lpips_tap(const void* feats, const float* lin, const int* pairs_dev, float* acc, float* workspace,
-                            int npairs, int HW, int C, void* stream) {
-    LB_REQUIRE(npairs > 0 && HW > 0 && C > 0, "lb_lpips_tap: sizes");
+static int lpips_tap_impl(LpipsPairs pp, const float* lin, float* acc, float* workspace, int npairs, int HW, int C,
+                          hipStream_t s) {
     int nblk = (HW + 3) / 4;
     if (nblk > 128) nblk = 128;
-    hipLaunchKernelGGL(lpips_tap_kernel, dim3(nblk, npairs), dim3(256), 0, (hipStream_t)stream, (const f16*)feats, lin,
-                       pairs_dev, workspace, HW, C);
+    hipLaunchKernelGGL(lpips_tap_kernel, dim3(nblk, npairs), dim3(256), 0, s, pp, lin, workspace, HW, C);
     int rc = lb_check_launch("lb_lpips_tap");
     if (rc) return rc;
-    hipLaunchKernelGGL(lpips_fold_kernel, dim3(npairs), dim3(64), 0, (hipStream_t)stream, workspace, acc, nblk, 1.f / (float)HW);
+    hipLaunchKernelGGL(lpips_fold_kernel, dim3(npairs), dim3(64), 0, s, workspace, acc, nblk, 1.f / (float)HW);
     return lb_check_launch("lb_lpips_tap(fold)");
+}
+// feats_a / feats_b: HOST arrays of npairs device pointers (<= 16); workspace: 16*128 floats
+extern "C" int lb_lpips_tap(const void* const* feats_a, const void* const* feats_b, const float* lin, float* acc,
+                            float* workspace, int npairs, int HW, int C, void* stream) {
+    LB_REQUIRE(npairs > 0 && npairs <= LPIPS_MAX_PAIRS && HW > 0 && C > 0, "lb_lpips_tap: sizes (<= 16 pairs)");
+    LpipsPairs pp;
+    for (int i = 0; i < npairs; ++i) { pp.a[i] = (const f16*)feats_a[i]; pp.b[i] = (const f16*)feats_b[i]; }
+    LB_DISPATCH("lb_lpips_tap", lpips_tap_impl(pp, lin, acc, workspace, npairs, HW, C, s));
 }
 
 // generic fill (zero LPIPS accumulators etc. without a runtime memset node)
@@ -244,6 +251,5 @@ __global__ void fill_f32_kernel(float* x, long n, float v) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] = v;
 }
 extern "C" int lb_fill_f32(void* x, long n, float v, void* stream) {
-    hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (float*)x, n, v);
-    return lb_check_launch("lb_fill_f32");
+    LB_DISPATCH_STMT("lb_fill_f32", hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, (float*)x, n, v));
 }

@@ -8,6 +8,7 @@
 //   lerp            latentblending/utils.py:97          (blending_engine.py:650)
 //   scale / step    diffusers_holder.py:330, 347-349, 356 (diffusers Euler schedulers)
 #include "lb_common.h"
+#include <vector>
 
 #define LB_MAX_PAIRS 16
 
@@ -132,51 +133,62 @@ __global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict_
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+struct SlerpChunk { SlerpPairs args; int cnt; bool vec_ok; };
+
 template <typename T>
-static int slerp_pairs_launch(const void* const* p0, const void* const* p1, void* const* out,
-                              const double* fracts, int npairs, long n, hipStream_t stream) {
-    for (int base = 0; base < npairs; base += LB_MAX_PAIRS) {
-        const int cnt = npairs - base < LB_MAX_PAIRS ? npairs - base : LB_MAX_PAIRS;
-        SlerpPairs args;
-        bool vec_ok = true;
-        for (int i = 0; i < cnt; ++i) {
-            args.p0[i] = p0[base + i]; args.p1[i] = p1[base + i]; args.out[i] = out[base + i];
-            args.fract[i] = fracts[base + i];
-            vec_ok = vec_ok && aligned16(args.p0[i]) && aligned16(args.p1[i]) && aligned16(args.out[i]);
-        }
-        constexpr int VEC = 16 / sizeof(T) > 8 ? 8 : 16 / sizeof(T);
-        if (vec_ok)
-            hipLaunchKernelGGL((slerp_pairs_kernel<T, VEC>), dim3(cnt), dim3(512), 0, stream, args, n);
+static int slerp_chunks_impl(const std::vector<SlerpChunk>& chunks, long n, hipStream_t stream) {
+    constexpr int VEC = 16 / sizeof(T) > 8 ? 8 : 16 / sizeof(T);
+    for (const SlerpChunk& c : chunks) {
+        if (c.vec_ok)
+            hipLaunchKernelGGL((slerp_pairs_kernel<T, VEC>), dim3(c.cnt), dim3(512), 0, stream, c.args, n);
         else
-            hipLaunchKernelGGL((slerp_pairs_kernel<T, 1>), dim3(cnt), dim3(512), 0, stream, args, n);
+            hipLaunchKernelGGL((slerp_pairs_kernel<T, 1>), dim3(c.cnt), dim3(512), 0, stream, c.args, n);
         int rc = lb_check_launch("lb_slerp_pairs");
         if (rc) return rc;
     }
     return 0;
 }
 
+static std::vector<SlerpChunk> slerp_make_chunks(const void* const* p0, const void* const* p1,
+                                                 void* const* out, const double* fracts, int npairs) {
+    std::vector<SlerpChunk> chunks;
+    for (int base = 0; base < npairs; base += LB_MAX_PAIRS) {
+        SlerpChunk c;
+        c.cnt = npairs - base < LB_MAX_PAIRS ? npairs - base : LB_MAX_PAIRS;
+        c.vec_ok = true;
+        for (int i = 0; i < c.cnt; ++i) {
+            c.args.p0[i] = p0[base + i]; c.args.p1[i] = p1[base + i]; c.args.out[i] = out[base + i];
+            c.args.fract[i] = fracts[base + i];
+            c.vec_ok = c.vec_ok && aligned16(c.args.p0[i]) && aligned16(c.args.p1[i]) && aligned16(c.args.out[i]);
+        }
+        chunks.push_back(c);
+    }
+    return chunks;
+}
+
 extern "C" int lb_slerp_pairs_f16(const void* const* p0, const void* const* p1, void* const* out,
                                   const double* fracts, int npairs, long n, void* stream) {
     LB_REQUIRE(npairs >= 0 && n > 0, "lb_slerp_pairs_f16: bad sizes");
-    return slerp_pairs_launch<f16>(p0, p1, out, fracts, npairs, n, (hipStream_t)stream);
+    const std::vector<SlerpChunk> chunks = slerp_make_chunks(p0, p1, out, fracts, npairs);
+    LB_DISPATCH("lb_slerp_pairs_f16", slerp_chunks_impl<f16>(chunks, n, s));
 }
 
 extern "C" int lb_slerp_pairs_f32(const void* const* p0, const void* const* p1, void* const* out,
                                   const double* fracts, int npairs, long n, void* stream) {
     LB_REQUIRE(npairs >= 0 && n > 0, "lb_slerp_pairs_f32: bad sizes");
-    return slerp_pairs_launch<float>(p0, p1, out, fracts, npairs, n, (hipStream_t)stream);
+    const std::vector<SlerpChunk> chunks = slerp_make_chunks(p0, p1, out, fracts, npairs);
+    LB_DISPATCH("lb_slerp_pairs_f32", slerp_chunks_impl<float>(chunks, n, s));
 }
 
 extern "C" int lb_slerp_pairs_f64(const void* const* p0, const void* const* p1, void* const* out,
                                   const double* fracts, int npairs, long n, void* stream) {
     LB_REQUIRE(npairs >= 0 && n > 0, "lb_slerp_pairs_f64: bad sizes");
-    return slerp_pairs_launch<double>(p0, p1, out, fracts, npairs, n, (hipStream_t)stream);
+    const std::vector<SlerpChunk> chunks = slerp_make_chunks(p0, p1, out, fracts, npairs);
+    LB_DISPATCH("lb_slerp_pairs_f64", slerp_chunks_impl<double>(chunks, n, s));
 }
 
-extern "C" int lb_slerp_batched_f16(const void* p0, const void* p1, void* out,
-                                    const double* fracts_dev, long npairs, long n, void* stream) {
-    LB_REQUIRE(npairs > 0 && n > 0 && n % 8 == 0, "lb_slerp_batched_f16: n must be a multiple of 8");
-    LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_slerp_batched_f16: 16-B alignment");
+static int slerp_batched_impl(const void* p0, const void* p1, void* out, const double* fracts_dev,
+                              long npairs, long n, hipStream_t stream) {
     const size_t stage_bytes = (size_t)n * 2 * sizeof(f16);
     const int staged = stage_bytes <= 128 * 1024 ? 1 : 0;
     const size_t smem = 512 + (staged ? stage_bytes : 0);
@@ -187,9 +199,16 @@ extern "C" int lb_slerp_batched_f16(const void* p0, const void* p1, void* out,
                             hipFuncAttributeMaxDynamicSharedMemorySize, 512 + 128 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)npairs), dim3(512), smem, (hipStream_t)stream,
+    hipLaunchKernelGGL(kern, dim3((unsigned)npairs), dim3(512), smem, stream,
                        (const f16*)p0, (const f16*)p1, (f16*)out, fracts_dev, n, staged);
     return lb_check_launch("lb_slerp_batched_f16");
+}
+
+extern "C" int lb_slerp_batched_f16(const void* p0, const void* p1, void* out,
+                                    const double* fracts_dev, long npairs, long n, void* stream) {
+    LB_REQUIRE(npairs > 0 && n > 0 && n % 8 == 0, "lb_slerp_batched_f16: n must be a multiple of 8");
+    LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_slerp_batched_f16: 16-B alignment");
+    LB_DISPATCH("lb_slerp_batched_f16", slerp_batched_impl(p0, p1, out, fracts_dev, npairs, n, s));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -237,19 +256,17 @@ extern "C" int lb_lerp_f16(const void* p0, const void* p1, void* out, long n, do
                            void* stream) {
     LB_REQUIRE(n > 0, "lb_lerp_f16: n");
     LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_lerp_f16: 16-B alignment");
-    hipLaunchKernelGGL(lerp_f16_kernel, dim3(ew_grid((n + 7) / 8, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const f16*)p0, (const f16*)p1, (f16*)out, n,
-                       (float)(1.0 - fract), (float)fract);
-    return lb_check_launch("lb_lerp_f16");
+    LB_DISPATCH_STMT("lb_lerp_f16", hipLaunchKernelGGL(lerp_f16_kernel, dim3(ew_grid((n + 7) / 8, 256)), dim3(256), 0, s,
+                                                  (const f16*)p0, (const f16*)p1, (f16*)out, n,
+                                                  (float)(1.0 - fract), (float)fract));
 }
 
 extern "C" int lb_lerp_f32(const void* p0, const void* p1, void* out, long n, double fract,
                            void* stream) {
     LB_REQUIRE(n > 0, "lb_lerp_f32: n");
-    hipLaunchKernelGGL(lerp_f32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)p0, (const float*)p1, (float*)out, n, (float)(1.0 - fract),
-                       (float)fract);
-    return lb_check_launch("lb_lerp_f32");
+    LB_DISPATCH_STMT("lb_lerp_f32", hipLaunchKernelGGL(lerp_f32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, s,
+                                                  (const float*)p0, (const float*)p1, (float*)out, n,
+                                                  (float)(1.0 - fract), (float)fract));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -280,10 +297,8 @@ __global__ void scale_input_kernel(const f16* __restrict__ x, f16* __restrict__ 
 extern "C" int lb_scale_model_input_f16(const void* x, void* out, const float* params_dev,
                                         long per_sample, int batch, int dup_for_cfg, void* stream) {
     LB_REQUIRE(per_sample > 0 && batch > 0, "lb_scale_model_input_f16: sizes");
-    hipLaunchKernelGGL(scale_input_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const f16*)x, (f16*)out, params_dev, per_sample, batch,
-                       dup_for_cfg);
-    return lb_check_launch("lb_scale_model_input_f16");
+    LB_DISPATCH_STMT("lb_scale_model_input_f16", hipLaunchKernelGGL(scale_input_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0, s,
+                                    (const f16*)x, (f16*)out, params_dev, per_sample, batch, dup_for_cfg));
 }
 
 // eps layout: cfg == 0: eps[b] ; cfg == 1: eps[0..B) = uncond, eps[B..2B) = text.
@@ -324,8 +339,7 @@ extern "C" int lb_euler_step_f16(const void* x, const void* eps, const void* noi
                                  int ancestral, void* stream) {
     LB_REQUIRE(per_sample > 0 && batch > 0, "lb_euler_step_f16: sizes");
     LB_REQUIRE(!ancestral || noise != nullptr, "lb_euler_step_f16: ancestral step needs noise");
-    hipLaunchKernelGGL(euler_step_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const f16*)x, (const f16*)eps, (const f16*)noise,
-                       (f16*)out, params_dev, per_sample, batch, cfg, ancestral);
-    return lb_check_launch("lb_euler_step_f16");
+    LB_DISPATCH_STMT("lb_euler_step_f16", hipLaunchKernelGGL(euler_step_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0, s,
+                                    (const f16*)x, (const f16*)eps, (const f16*)noise, (f16*)out, params_dev,
+                                    per_sample, batch, cfg, ancestral));
 }

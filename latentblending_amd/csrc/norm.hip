@@ -146,14 +146,11 @@ extern "C" long lb_groupnorm_workspace_bytes(int B, int groups) {
 }
 
 // x: [B][HW][ldx] (fp16, or fp32 when x_is_f32), y: [B][HW][ldy] fp16, gamma/beta fp32 [C]
-extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta,
-                                 void* workspace, int B, int HW, int C, int ldx, int ldy, int groups,
-                                 float eps, int silu, int x_is_f32, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    LB_REQUIRE(B > 0 && HW > 0 && C > 0, "lb_groupnorm_nhwc: sizes");
+static int groupnorm_impl(const void* x, void* y, const float* gamma, const float* beta,
+                          void* workspace, int B, int HW, int C, int ldx, int ldy, int groups,
+                          float eps, int silu, int x_is_f32, hipStream_t stream) {
     LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "lb_groupnorm_nhwc: C/ld multiple of 8");
     LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_nhwc: groups");
-    LB_REQUIRE(C <= 4096, "lb_groupnorm_nhwc: C <= 4096");
     const int vecs = C / 8;
     int chunk_px = (HW + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS;
     if (chunk_px < 32) chunk_px = 32;
@@ -181,6 +178,17 @@ extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, con
         hipLaunchKernelGGL((gn_apply_kernel<f16>), grid2, dim3(256), 0, stream, (const f16*)x,
                            partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu);
     return lb_check_launch("lb_groupnorm_nhwc(apply)");
+}
+
+extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta,
+                                 void* workspace, int B, int HW, int C, int ldx, int ldy, int groups,
+                                 float eps, int silu, int x_is_f32, void* stream) {
+    LB_REQUIRE(B > 0 && HW > 0 && C > 0, "lb_groupnorm_nhwc: sizes");
+    LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "lb_groupnorm_nhwc: C/ld multiple of 8");
+    LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_nhwc: groups");
+    LB_REQUIRE(C <= 4096, "lb_groupnorm_nhwc: C <= 4096");
+    LB_DISPATCH("lb_groupnorm_nhwc", groupnorm_impl(x, y, gamma, beta, workspace, B, HW, C, ldx, ldy, groups,
+                                                    eps, silu, x_is_f32, s));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -235,7 +243,6 @@ extern "C" int lb_layernorm_f16(const void* x, void* y, const float* gamma, cons
                                 int C, int ldx, int ldy, float eps, void* stream) {
     LB_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "lb_layernorm_f16: C multiple of 8, <= 2048");
     LB_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "lb_layernorm_f16: ld multiple of 8");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, gamma, beta, (f16*)y, M, C, ldx, ldy, eps);
-    return lb_check_launch("lb_layernorm_f16");
+    LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s,
+                       (const f16*)x, gamma, beta, (f16*)y, M, C, ldx, ldy, eps));
 }

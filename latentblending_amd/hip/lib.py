@@ -70,18 +70,30 @@ SIGNATURES = {
     "lb_sinusoid_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lb_copy_cols_f16": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "lb_cast_f16_to_f32": (_i, [_vp, _vp, _l, _vp]),
-    "lb_cast_f32_to_f16": (_i, [_vp, _vp, _l, _vp]),
+    "lb_cast_f32_to_f16": (_i, [_vp, _vp, _l, _f, _vp]),
     "lb_nchw_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lb_nhwc_to_nchw_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lb_postprocess_u8": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "lb_lpips_prep_u8": (_i, [_vp, _vp, _l, _vp]),
     "lb_maxpool3s2_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "lb_lpips_tap": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "lb_lpips_tap": (_i, [c_void_pp, c_void_pp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "lb_fill_f32": (_i, [_vp, _l, _f, _vp]),
+    "lb_copy_d2d": (_i, [_vp, _vp, _l, _vp]),
+    "lb_program_create": (_vp, []),
+    "lb_program_destroy": (None, [_vp]),
+    "lb_program_begin_record": (_i, [_vp]),
+    "lb_program_end_record": (_i, [_vp]),
+    "lb_program_num_ops": (_i, [_vp]),
+    "lb_program_op_name": (C.c_char_p, [_vp, _i]),
+    "lb_program_run": (_i, [_vp, _vp]),
+    "lb_program_run_range": (_i, [_vp, _i, _i, _vp]),
+    "lb_program_instantiate": (_i, [_vp]),
+    "lb_program_launch": (_i, [_vp, _vp]),
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning"}
+             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_program_create",
+             "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 
 def _load():

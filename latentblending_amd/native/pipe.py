@@ -1,0 +1,340 @@
+"""``NativeSDXLPipe`` — the SDXL pipeline object of the MI355X path.
+
+It is two things at once:
+
+1. a **duck-typed diffusers pipeline** (SURVEY.md Appendix A): every attribute the reference's
+   ``DiffusersHolder`` touches exists with the same meaning (``unet(...)``, ``scheduler``,
+   ``vae.decode``, ``encode_prompt``, ``prepare_latents``, ``image_processor`` ...), so the
+   unchanged reference host code can drive it step by step.  The class is named
+   ``StableDiffusionXLPipeline`` because the reference dispatches on that class name
+   (/root/reference/latentblending/diffusers_holder.py:41);
+2. the **native fast path** (``is_lb_native``) used by ``latentblending_amd.DiffusersHolder``: the
+   whole restartable denoising loop for one branch or a BATCH of branches — crossfeed slerps,
+   input scaling, UNet program, CFG + Euler(-ancestral) update — with device-resident state and
+   one recorded launch program per UNet forward; VAE decode to uint8 frames on device; LPIPS on
+   device frames with cached features.
+
+Text encoders: CLIP weights/vocabularies are not available offline, so ``encode_prompt`` returns
+seeded synthetic embeddings of the right shapes unless ``text_encoder_fn`` is supplied
+(the step before the hot path).
+"""
+from __future__ import annotations
+
+import zlib
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+from ..hip import ops
+from ..hip.lib import api
+from .frames import DeviceImage
+from .lpips import NativeLPIPS
+from .scheduler import NativeEulerScheduler
+from .unet import NativeUNet, UNetConfig, UNetProgram
+from .vae import NativeVAEDecoder, VAEConfig, VAEProgram
+from .weights import SyntheticProvider
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _synthetic_embedding(text: str, shape, salt: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed((zlib.crc32(text.encode()) + 7919 * salt) & 0x7FFFFFFF)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+class _UNetFacade:
+    def __init__(self, pipe):
+        self._pipe = pipe
+        c = pipe.unet_cfg
+        self.config = SimpleNamespace(sample_size=c.sample_size, in_channels=c.in_channels,
+                                      time_cond_proj_dim=c.time_cond_proj_dim)
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, timestep_cond=None,
+                 cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=False):
+        pipe = self._pipe
+        B, _, L, _ = sample.shape
+        prog = pipe.unet_program(B, L)
+        prog.set_conditioning(encoder_hidden_states, added_cond_kwargs["text_embeds"],
+                              added_cond_kwargs["time_ids"])
+        t = torch.as_tensor(timestep, dtype=F32).reshape(-1).expand(B)
+        return (prog.forward(sample.to(F16), t.to(sample.device)).clone(),)
+
+
+class _VAEFacade:
+    def __init__(self, pipe):
+        self._pipe = pipe
+        c = pipe.vae_cfg
+        self.dtype = F16
+        self.config = SimpleNamespace(force_upcast=False, scaling_factor=c.scaling_factor)
+        self.post_quant_conv = SimpleNamespace(parameters=lambda: iter([torch.zeros(1, dtype=F16)]))
+
+    def decode(self, z, return_dict=False):
+        """z = latents / scaling_factor -> float image [B,3,H,W] (diffusers convention)."""
+        prog = self._pipe.vae_program(z.shape[0], z.shape[-1])
+        prog.decode((z.float() * self._pipe.vae_cfg.scaling_factor).to(F16))
+        return (prog.image_f32[..., :3].permute(0, 3, 1, 2).clone(),)
+
+    def to(self, *a, **k):
+        return self
+
+
+class _ImageProcessor:
+    @staticmethod
+    def postprocess(image, output_type="pil"):
+        x = image.permute(0, 2, 3, 1).contiguous()
+        if x.shape[-1] < 4:
+            x = torch.cat([x, torch.zeros_like(x[..., :1])], dim=-1).contiguous()
+        u8 = ops.postprocess_u8(x.float())
+        if output_type == "np":
+            return [f.cpu().numpy().astype(np.float32) / 255.0 for f in u8]
+        return [DeviceImage(f) for f in u8]
+
+
+class StableDiffusionXLPipeline:
+    is_lb_native = True
+
+    def __init__(self, turbo: bool = True, unet_cfg: Optional[UNetConfig] = None,
+                 vae_cfg: Optional[VAEConfig] = None, unet_provider=None, vae_provider=None,
+                 lpips_provider=None, device="cuda", seed: int = 0, name_or_path: Optional[str] = None,
+                 text_encoder_fn=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("NativeSDXLPipe needs an MI355X (HIP device); there is no CPU fallback")
+        self.device = torch.device(device)
+        self._execution_device = self.device
+        self.unet_cfg = unet_cfg or UNetConfig(sample_size=64 if turbo else 128)
+        self.vae_cfg = vae_cfg or VAEConfig()
+        self._name_or_path = name_or_path or ("stabilityai/sdxl-turbo" if turbo else
+                                              "stabilityai/stable-diffusion-xl-base-1.0")
+        self.dtype = F16
+        self.unet_native = NativeUNet(self.unet_cfg, unet_provider or SyntheticProvider(seed), self.device)
+        self.vae_native = NativeVAEDecoder(self.vae_cfg, vae_provider or SyntheticProvider(seed + 1), self.device)
+        self.lpips_metric = NativeLPIPS(lpips_provider or SyntheticProvider(7), self.device)
+        self.scheduler = NativeEulerScheduler(ancestral=turbo, device=self.device)
+        self.unet = _UNetFacade(self)
+        self.vae = _VAEFacade(self)
+        self.image_processor = _ImageProcessor()
+        self.vae_scale_factor = self.vae_cfg.scale_factor
+        self.default_sample_size = self.unet_cfg.sample_size
+        self.text_encoder_2 = None
+        self.text_encoder_fn = text_encoder_fn
+        self._guidance_scale = 0.0 if turbo else 5.0
+        self._guidance_rescale = 0.0
+        self._clip_skip = None
+        self._cross_attention_kwargs = None
+        self._denoising_end = None
+        self._interrupt = False
+        self._num_timesteps = 0
+        self._unet_programs: Dict[Tuple[int, int], UNetProgram] = {}
+        self._vae_programs: Dict[Tuple[int, int], VAEProgram] = {}
+        self._use_graphs = False
+        self._feat_scratch: Dict[int, list] = {}
+        self.stats = {"unet_forwards": 0, "unet_samples": 0, "vae_decodes": 0, "slerps": 0, "lpips_pairs": 0}
+
+    # ---- diffusers duck type ------------------------------------------------------------
+    guidance_scale = property(lambda s: s._guidance_scale)
+    guidance_rescale = property(lambda s: s._guidance_rescale)
+    cross_attention_kwargs = property(lambda s: s._cross_attention_kwargs)
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None
+
+    def to(self, *_a, **_k):
+        return self
+
+    def upcast_vae(self):
+        pass
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        return {"generator": generator}
+
+    def encode_prompt(self, prompt=None, prompt_2=None, device=None, num_images_per_prompt=1,
+                      do_classifier_free_guidance=True, negative_prompt=None, negative_prompt_2=None, **_):
+        c = self.unet_cfg
+
+        def embed(text):
+            if self.text_encoder_fn is not None:
+                pe, pooled = self.text_encoder_fn(text)
+            else:
+                pe = _synthetic_embedding(text, (1, 77, c.cross_dim), 1)
+                pooled = _synthetic_embedding(text, (1, c.pooled_dim), 2)
+            return pe.to(self.device, F16), pooled.to(self.device, F16)
+
+        text = prompt if isinstance(prompt, str) else prompt[0]
+        pe, pooled = embed(text)
+        if not do_classifier_free_guidance:
+            return pe, None, pooled, None
+        neg = negative_prompt[0] if isinstance(negative_prompt, (list, tuple)) and negative_prompt else negative_prompt
+        if neg:
+            npe, npooled = embed(neg)
+        else:
+            npe, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
+        return pe, npe, pooled, npooled
+
+    def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):
+        """Seeded noise drawn on the HOST (so a seed means the same latent on every device and in
+        the CPU oracle), scaled by the scheduler's initial sigma."""
+        shape = (batch, channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        host_gen = torch.Generator().manual_seed(generator.initial_seed())
+        z = torch.randn(shape, generator=host_gen, dtype=torch.float32).to(dtype)
+        return (z * self.scheduler.init_noise_sigma).to(self.device)
+
+    def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype,
+                          text_encoder_projection_dim=None):
+        ids = list(original_size) + list(crops_coords_top_left) + list(target_size)
+        return torch.tensor([ids], dtype=dtype, device=self.device)
+
+    # ---- programs -----------------------------------------------------------------------
+    def unet_program(self, B: int, L: int) -> UNetProgram:
+        key = (B, L)
+        if key not in self._unet_programs:
+            prog = self.unet_native.build(B, L)
+            if self._use_graphs:
+                prog.enable_graphs()
+            self._unet_programs[key] = prog
+        return self._unet_programs[key]
+
+    def vae_program(self, B: int, L: int) -> VAEProgram:
+        key = (B, L)
+        if key not in self._vae_programs:
+            prog = self.vae_native.build(B, L)
+            if self._use_graphs:
+                prog.prog.instantiate()
+            self._vae_programs[key] = prog
+        return self._vae_programs[key]
+
+    def enable_graphs(self, flag: bool = True):
+        self._use_graphs = bool(flag)
+        if flag:
+            for p in self._unet_programs.values():
+                p.enable_graphs()
+            for p in self._vae_programs.values():
+                p.prog.instantiate()
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # ---- native fast path -----------------------------------------------------------------
+    def _time_ids_row(self) -> List[float]:
+        side = float(self.default_sample_size * self.vae_scale_factor)
+        return [side, side, 0.0, 0.0, side, side]      # native size, not render size (reference quirk)
+
+    def native_run_diffusion(self, text_embeddings, latents_start, idx_start, list_latents_mixing, coeffs,
+                             num_inference_steps, guidance_scale):
+        return self.native_run_diffusion_batch([text_embeddings], [latents_start], idx_start,
+                                               [list_latents_mixing], [coeffs], num_inference_steps,
+                                               [guidance_scale])[0]
+
+    @torch.no_grad()
+    def native_run_diffusion_batch(self, conds: Sequence[tuple], starts: Sequence[torch.Tensor], idx_start: int,
+                                   mixings: Sequence[Optional[list]], coeffs_list: Sequence[Sequence[float]],
+                                   num_inference_steps: int, guidance_scales: Sequence[float]):
+        """Denoise G branches in lock-step from ``idx_start``.  Returns per branch a list with one
+        entry per step (``None`` below ``idx_start``, else the [1,4,L,L] latent after that step)."""
+        G = len(conds)
+        sched = self.scheduler
+        if sched.num_inference_steps != num_inference_steps:
+            sched.set_timesteps(num_inference_steps)
+        self._guidance_scale = float(guidance_scales[-1])
+        cfg = max(float(g) for g in guidance_scales) > 1 and self.unet.config.time_cond_proj_dim is None
+        L = starts[0].shape[-1]
+        per_sample = starts[0][0].numel()
+        prog = self.unet_program(G * (2 if cfg else 1), L)
+
+        pos_ctx = torch.cat([c[0] for c in conds]).to(self.device, F16)
+        pos_pool = torch.cat([c[2] for c in conds]).to(self.device, F16)
+        if cfg:
+            neg_ctx = torch.cat([c[1] for c in conds]).to(self.device, F16)
+            neg_pool = torch.cat([c[3] for c in conds]).to(self.device, F16)
+            ctx, pooled = torch.cat([neg_ctx, pos_ctx]), torch.cat([neg_pool, pos_pool])
+        else:
+            ctx, pooled = pos_ctx, pos_pool
+        time_ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
+        prog.set_conditioning(ctx, pooled, time_ids)
+
+        latents = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in starts]).contiguous()
+        trajs: List[List[Optional[torch.Tensor]]] = [[None] * idx_start for _ in range(G)]
+        stream = torch.cuda.current_stream().cuda_stream
+        # every step's scalar coefficients in ONE upload: [steps][G][8]
+        rows = [sched.step_row(i, float(guidance_scales[g])) for i in range(idx_start, num_inference_steps)
+                for g in range(G)]
+        params_all = ops.step_params(rows, self.device).view(-1, G, 8) if rows else None
+        for i in range(idx_start, num_inference_steps):
+            if i > 0:
+                mix = [g for g in range(G) if coeffs_list[g][i] > 0]
+                if mix:
+                    outs = ops.slerp_pairs([latents[g:g + 1] for g in mix],
+                                           [mixings[g][i - 1].to(self.device, F16) for g in mix],
+                                           [float(coeffs_list[g][i]) for g in mix])
+                    self.stats["slerps"] += len(mix)
+                    if len(mix) == G:
+                        latents = torch.cat(outs)
+                    else:
+                        latents = latents.clone()
+                        for g, o in zip(mix, outs):
+                            latents[g:g + 1] = o
+            params = params_all[i - idx_start]
+            api.lb_scale_model_input_f16(latents.data_ptr(), prog.x_in.data_ptr(), params.data_ptr(), per_sample, G,
+                                         int(cfg), stream)
+            prog.tvals.fill_(float(sched.timesteps_np[i]))
+            prog.prog_step.launch(stream)
+            self.stats["unet_forwards"] += 1
+            self.stats["unet_samples"] += prog.B
+            noise = None
+            if sched.ancestral:
+                noise = torch.cat([sched.draw_noise((1,) + tuple(latents.shape[1:]), self.device) for _ in range(G)])
+            latents = ops.euler_step(latents, prog.eps, params, noise=noise, cfg=cfg, ancestral=sched.ancestral)
+            for g in range(G):
+                trajs[g].append(latents[g:g + 1])
+        return trajs
+
+    @torch.no_grad()
+    def native_latent2image_batch(self, latents: Sequence[torch.Tensor], output_type="pil"):
+        z = torch.cat([t.to(self.device, F16).reshape(1, -1, t.shape[-2], t.shape[-1]) for t in latents])
+        prog = self.vae_program(z.shape[0], z.shape[-1])
+        frames = prog.decode(z).clone()
+        self.stats["vae_decodes"] += z.shape[0]
+        if output_type == "np":
+            return [f.cpu().numpy().astype(np.float32) / 255.0 for f in frames]
+        return [DeviceImage(f) for f in frames]
+
+    def native_latent2image(self, latents, output_type="pil"):
+        return self.native_latent2image_batch([latents], output_type)[0]
+
+    @torch.no_grad()
+    def native_frame_distances(self, pairs) -> List[float]:
+        """LPIPS distance for (frameA, frameB) pairs of ``DeviceImage`` / PIL / numpy frames."""
+        frames = []
+        for a, b in pairs:
+            frames += [a, b]
+        missing, seen = [], set()
+        for f in frames:
+            if getattr(f, "_lb_feats", None) is None and id(f) not in seen:
+                seen.add(id(f))
+                missing.append(f)
+        if missing:
+            u8 = torch.stack([self._frame_u8(f) for f in missing])
+            taps = self.lpips_metric.features(u8)
+            for n, f in enumerate(missing):
+                feats = [t[n] for t in taps]
+                try:
+                    f._lb_feats = feats
+                except AttributeError:
+                    pass
+                self._feat_scratch[id(f)] = feats
+        feat_of = lambda f: getattr(f, "_lb_feats", None) or self._feat_scratch[id(f)]
+        d = self.lpips_metric.distances([(feat_of(a), feat_of(b)) for a, b in pairs])
+        self.stats["lpips_pairs"] += len(pairs)
+        self._feat_scratch.clear()
+        return [float(v) for v in d.tolist()]
+
+    def _frame_u8(self, f) -> torch.Tensor:
+        if isinstance(f, DeviceImage):
+            return f._lb_u8.to(self.device)
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(f, dtype=np.uint8))).to(self.device)
+
+
+NativeSDXLPipe = StableDiffusionXLPipeline

@@ -1,0 +1,196 @@
+"""Device-side plumbing for the native model programs.
+
+* ``Arena``   — size-class pool over torch device tensors.  A recorded program replays in stream
+  order, so a buffer can be handed to the next op as soon as its last reader has been emitted;
+  reuse keeps the working set of a UNet forward inside L2 / Infinity Cache instead of walking
+  through fresh HBM for every op.
+* ``Program`` — owner of a C++ launch program (``lb_program_*``): ``with prog.record(): ...`` runs
+  the emitting Python ONCE; afterwards ``prog.launch()`` replays ~1000 kernel launches from C++
+  (optionally as one hipGraph) with a single ctypes call.
+* ``Emitter`` — thin typed helpers that fill the C structs and call the launchers (in record mode
+  these calls are captured, in eager mode they launch immediately — same code path).
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ..hip import lib
+from ..hip.lib import api, LbGemmParams, LbAttnParams
+
+F16, F32 = torch.float16, torch.float32
+
+
+class Arena:
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[int, List[torch.Tensor]] = {}
+        self.all: List[torch.Tensor] = []
+        self.bytes_allocated = 0
+
+    @staticmethod
+    def _cls(nbytes: int) -> int:
+        return max(512, (nbytes + 511) // 512 * 512)
+
+    def alloc(self, shape, dtype=F16) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= int(s)
+        esz = torch.empty((), dtype=dtype).element_size()
+        cls = self._cls(n * esz)
+        pool = self.free.get(cls)
+        if pool:
+            raw = pool.pop()
+        else:
+            raw = torch.empty(cls, dtype=torch.uint8, device=self.device)
+            self.all.append(raw)
+            self.bytes_allocated += cls
+        t = raw[: n * esz].view(dtype).view(*shape)
+        t._lb_raw = raw
+        return t
+
+    def release(self, t: Optional[torch.Tensor]) -> None:
+        if t is None:
+            return
+        raw = getattr(t, "_lb_raw", None)
+        if raw is None:
+            return
+        t._lb_raw = None
+        self.free.setdefault(raw.numel(), []).append(raw)
+
+
+class Program:
+    def __init__(self, name: str = "program"):
+        self.name = name
+        self.handle = api.lb_program_create()
+        self.keep: List[object] = []       # tensors / arenas the recorded pointers refer to
+        self.graph_ready = False
+
+    def __del__(self):
+        try:
+            if self.handle:
+                api.lb_program_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @contextlib.contextmanager
+    def record(self):
+        api.lb_program_begin_record(self.handle)
+        try:
+            yield self
+        finally:
+            api.lb_program_end_record(self.handle)
+
+    @property
+    def num_ops(self) -> int:
+        return api.lb_program_num_ops(self.handle)
+
+    def op_names(self) -> List[str]:
+        return [api.lb_program_op_name(self.handle, i).decode() for i in range(self.num_ops)]
+
+    def run(self, stream: Optional[int] = None) -> None:
+        api.lb_program_run(self.handle, stream if stream is not None else _stream())
+
+    def run_range(self, begin: int, end: int, stream: Optional[int] = None) -> None:
+        api.lb_program_run_range(self.handle, begin, end, stream if stream is not None else _stream())
+
+    def instantiate(self) -> None:
+        api.lb_program_instantiate(self.handle)
+        self.graph_ready = True
+
+    def launch(self, stream: Optional[int] = None) -> None:
+        api.lb_program_launch(self.handle, stream if stream is not None else _stream())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class Emitter:
+    """Helpers shared by the UNet / VAE / LPIPS program builders.  All tensors are views into an
+    ``Arena`` (activations) or packed weights; nothing here synchronises or allocates through
+    torch while a program is being recorded except via the arena."""
+
+    def __init__(self, arena: Arena):
+        self.arena = arena
+        self.device = arena.device
+        # one split-K slab region and one GroupNorm workspace shared by all ops of a program
+        self.ws_gemm: Optional[torch.Tensor] = None
+        self.ws_gn: Optional[torch.Tensor] = None
+
+    # -- workspaces -------------------------------------------------------------------------
+    def _gemm_ws(self, M: int, N: int) -> torch.Tensor:
+        need = api.lb_gemm_workspace_bytes(M, N) // 4
+        if self.ws_gemm is None or self.ws_gemm.numel() < need:
+            self.ws_gemm = torch.empty(max(need, 1 << 22), dtype=F32, device=self.device)
+        return self.ws_gemm
+
+    def _gn_ws(self, B: int, groups: int) -> torch.Tensor:
+        need = api.lb_groupnorm_workspace_bytes(B, groups) // 8
+        if self.ws_gn is None or self.ws_gn.numel() < need:
+            self.ws_gn = torch.empty(need, dtype=torch.float64, device=self.device)
+        return self.ws_gn
+
+    # -- dense ------------------------------------------------------------------------------
+    def gemm(self, A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, bias=None,
+             residual=None, rowvec=None, rows_per_batch: int = 0, flags: int = 0, alpha: float = 1.0,
+             lda: Optional[int] = None, ldc: Optional[int] = None, ldr: Optional[int] = None,
+             ld_rowvec: Optional[int] = None, conv: Optional[dict] = None, splitk: bool = True):
+        p = LbGemmParams()
+        N, K = W.shape
+        p.A, p.W, p.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+        p.bias, p.residual, p.rowvec = _p(bias), _p(residual), _p(rowvec)
+        p.M, p.N, p.K, p.ldw = M, N, K, W.stride(0)
+        n_out = N // 2 if flags & lib.GEMM_GEGLU else N
+        if conv is not None:
+            p.conv = 1
+            for k in ("Hin", "Win", "Cin", "Hout", "Wout", "KH", "KW", "stride", "pad", "ups", "ldx"):
+                setattr(p, k, int(conv[k]))
+        else:
+            p.lda = lda if lda is not None else K
+        p.ldc = ldc if ldc is not None else (M if flags & lib.GEMM_TRANS_OUT else n_out)
+        p.ldr = ldr if ldr is not None else n_out
+        if rowvec is not None:
+            p.ld_rowvec, p.rows_per_batch = ld_rowvec if ld_rowvec is not None else N, rows_per_batch
+        p.alpha, p.flags = alpha, flags
+        if splitk and not (flags & lib.GEMM_GEGLU):
+            p.partial = self._gemm_ws(M, N).data_ptr()
+        api.lb_gemm_f16(C.byref(p), _stream())
+        return out
+
+    def groupnorm(self, x: torch.Tensor, out: torch.Tensor, gamma, beta, *, B: int, HW: int, C_: int,
+                  eps: float, silu: bool, groups: int = 32, ldx: Optional[int] = None):
+        api.lb_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                              self._gn_ws(B, groups).data_ptr(), B, HW, C_, ldx or C_, C_, groups, eps,
+                              int(silu), int(x.dtype == F32), _stream())
+        return out
+
+    def layernorm(self, x, out, gamma, beta, *, M: int, C_: int, eps: float = 1e-5):
+        api.lb_layernorm_f16(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, C_, C_, C_,
+                             eps, _stream())
+        return out
+
+    def attention(self, q_ptr: int, k_ptr: int, vt_ptr: int, out: torch.Tensor, *, B, H, Sq, Skv, valid,
+                  ldq, ldk, ldvt, ldo):
+        p = LbAttnParams()
+        p.Q, p.K, p.Vt, p.O = q_ptr, k_ptr, vt_ptr, out.data_ptr()
+        p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, valid
+        p.ldq, p.ldk, p.ldvt, p.ldo = ldq, ldk, ldvt, ldo
+        p.scale = 0.125
+        api.lb_attn_fwd_d64(C.byref(p), _stream())
+        return out
+
+    def copy_cols(self, src, dst, *, rows, cols, ld_src, ld_dst, dst_off):
+        api.lb_copy_cols_f16(src.data_ptr(), dst.data_ptr(), rows, cols, ld_src, ld_dst, dst_off, _stream())
+
+    def copy(self, dst: torch.Tensor, src: torch.Tensor):
+        assert dst.numel() * dst.element_size() == src.numel() * src.element_size()
+        api.lb_copy_d2d(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), _stream())

@@ -1,0 +1,100 @@
+"""Host side of the Euler / Euler-ancestral schedulers (diffusers 0.25 semantics for SDXL base
+and SDXL-Turbo).  Only the sigma / timestep tables and per-step scalar
+coefficients live here (float64 numpy); the tensor work — ``x / sqrt(sigma^2+1)``, CFG combine
+and the update — runs in ``lb_scale_model_input_f16`` / ``lb_euler_step_f16``.
+
+Reference call sites: /root/reference/latentblending/diffusers_holder.py:42,53,247 (set_timesteps),
+:301 (order), :330 (scale_model_input), :356 (step).  Known answers: tests/golden/scheduler.json.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..hip import ops
+
+NUM_TRAIN_TIMESTEPS = 1000
+
+
+def _sigma_table() -> np.ndarray:
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, NUM_TRAIN_TIMESTEPS, dtype=np.float64) ** 2
+    alphas_cumprod = np.cumprod(1.0 - betas)
+    return ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
+
+
+class NativeEulerScheduler:
+    order = 1
+
+    def __init__(self, ancestral: bool, timestep_spacing: Optional[str] = None, device="cuda"):
+        self.ancestral = ancestral
+        self.timestep_spacing = timestep_spacing or ("trailing" if ancestral else "leading")
+        self.device = device
+        self._table = _sigma_table()
+        self.noise_source = None          # callable(shape) -> tensor; None = device RNG
+        self._step_index = None
+        self.set_timesteps(30)
+
+    # ---- tables -----------------------------------------------------------------------------
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        n = int(num_inference_steps)
+        if self.timestep_spacing == "trailing":
+            ts = np.round(np.arange(NUM_TRAIN_TIMESTEPS, 0, -NUM_TRAIN_TIMESTEPS / n)) - 1
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, n) * (NUM_TRAIN_TIMESTEPS // n)).round()[::-1].copy() + 1   # steps_offset = 1
+        else:
+            raise ValueError(f"unsupported timestep_spacing {self.timestep_spacing}")
+        ts = ts.astype(np.float32)
+        sig = np.interp(ts, np.arange(0, NUM_TRAIN_TIMESTEPS), self._table)
+        self.sigmas_np = np.concatenate([sig, [0.0]]).astype(np.float32)
+        self.timesteps_np = ts
+        self.timesteps = torch.from_numpy(ts)                  # host tensor: iterating it never syncs
+        self.sigmas = torch.from_numpy(self.sigmas_np)
+        self.num_inference_steps = n
+        self._step_index = None
+
+    @property
+    def init_noise_sigma(self) -> float:
+        m = float(self.sigmas_np.max())
+        return m if self.timestep_spacing in ("linspace", "trailing") else (m * m + 1) ** 0.5
+
+    def index_of(self, t) -> int:
+        hits = np.nonzero(self.timesteps_np == float(t))[0]
+        return int(hits[0])
+
+    def step_row(self, i: int, guidance: float = 0.0) -> Tuple[float, float, float, float, float]:
+        """(sigma_from, sigma_next, sigma_up, guidance, dt) for ``lb_euler_step_f16``; computed in
+        Python floats exactly like the scheduler's own scalar arithmetic."""
+        s_from, s_to = float(self.sigmas_np[i]), float(self.sigmas_np[i + 1])
+        if self.ancestral:
+            s_up = (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5
+            s_down = (s_to ** 2 - s_up ** 2) ** 0.5
+            return (s_from, s_down, s_up, guidance, s_down - s_from)
+        return (s_from, s_to, 0.0, guidance, s_to - s_from)
+
+    # ---- diffusers-style tensor API (generic holder loop / foreign callers) ------------------
+    def _locate(self, t) -> int:
+        if self._step_index is None:
+            self._step_index = self.index_of(float(t))
+        return self._step_index
+
+    def scale_model_input(self, sample: torch.Tensor, timestep) -> torch.Tensor:
+        i = self._locate(timestep)
+        params = ops.step_params([self.step_row(i)] * sample.shape[0], sample.device)
+        return ops.scale_model_input(sample.contiguous(), params)
+
+    def draw_noise(self, shape, device) -> torch.Tensor:
+        if self.noise_source is not None:
+            return self.noise_source(tuple(shape)).to(device=device, dtype=torch.float16)
+        return torch.randn(shape, device=device, dtype=torch.float16)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=False, **_):
+        i = self._locate(timestep)
+        B = sample.shape[0]
+        params = ops.step_params([self.step_row(i)] * B, sample.device)
+        noise = self.draw_noise(sample.shape, sample.device) if self.ancestral else None
+        out = ops.euler_step(sample.contiguous(), model_output.contiguous(), params, noise=noise,
+                             ancestral=self.ancestral)
+        self._step_index += 1
+        return (out,)

@@ -1,0 +1,450 @@
+"""Native SDXL UNet: weight packing + launch-program builder for gfx950.
+
+Architecture = diffusers ``UNet2DConditionModel`` as configured for SDXL base / turbo (SURVEY.md
+Appendix B.1; reached from /root/reference/latentblending/diffusers_holder.py:336).  What is
+MI355X-specific here:
+
+* NHWC fp16 activations end to end: a feature map IS the [tokens, channels] matrix the
+  transformer blocks consume, so resnets and transformers share buffers with no permutes;
+* every Linear / Conv is one launch of the MFMA GEMM / implicit-GEMM kernel with its bias,
+  time-embedding add, residual add or GEGLU fused into the epilogue; nearest-2x upsampling and
+  stride-2 downsampling are folded into the conv's gather;
+* work that does not depend on the image is batched into a few fat GEMMs instead of hundreds of
+  tiny launches: all 17 resnets' time-embedding projections = 1 GEMM; all 70 cross-attention
+  K projections = 1 GEMM and all V^T projections = 1 GEMM over the (padded) text context, kept
+  in a separate *conditioning program* that only re-runs when the conditioning changes;
+* V is produced directly transposed by swapping the GEMM operands (out = W_v . X^T), which is
+  the layout the attention kernel's second MFMA consumes without any cross-lane traffic;
+* the whole forward is recorded once per (batch, latent size) and replayed from C++ / hipGraph.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from ..hip import lib
+from ..hip.lib import api
+from .runtime import Arena, Emitter, Program, F16, F32, _stream
+
+CTX_TOKENS = 77
+CTX_PAD = 80
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_channels: Tuple[int, ...] = (320, 640, 1280)
+    layers_per_block: int = 2
+    transformer_depth: Tuple[int, ...] = (0, 2, 10)
+    head_dim: int = 64
+    cross_dim: int = 2048
+    pooled_dim: int = 1280
+    add_time_dim: int = 256
+    sample_size: int = 128
+    norm_groups: int = 32
+    time_cond_proj_dim: Optional[int] = None
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_channels[0] * 4
+
+    @property
+    def add_in_dim(self) -> int:
+        return self.pooled_dim + 6 * self.add_time_dim
+
+
+def _pad(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class NativeUNet:
+    def __init__(self, cfg: UNetConfig, provider, device="cuda"):
+        assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
+        self.cfg, self.device = cfg, torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self.temb_slices: Dict[str, Tuple[int, int]] = {}      # resnet -> (offset, cout) in the fused projection
+        self.ctx_slices: Dict[str, Tuple[int, int]] = {}       # transformer block -> (offset, C) in fused ctx K / V
+        self._load(provider)
+
+    # ------------------------------------------------------------------ weights -----------
+    def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _linear(self, pv, name, cin, cout, bias=True, gain=1.0, keep_host=False):
+        w = pv.weight(name + ".weight", (cout, cin), cin, gain)
+        if not keep_host:
+            self.w[name + ".weight"] = self._dev(w, F16)
+        if bias:
+            self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", cout), F32)
+        return w
+
+    def _conv(self, pv, name, cin, cout, k, gain=1.0):
+        w = pv.weight(name + ".weight", (cout, cin, k, k), cin * k * k, gain)
+        cin_p, cout_p = _pad(cin, 8), _pad(cout, 4)
+        packed = torch.zeros(cout_p, k, k, cin_p, dtype=torch.float32)
+        packed[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+        self.w[name + ".weight"] = self._dev(packed.reshape(cout_p, k * k * cin_p), F16)
+        b = torch.zeros(cout_p, dtype=torch.float32)
+        b[:cout] = pv.bias(name + ".bias", cout)
+        self.w[name + ".bias"] = self._dev(b, F32)
+
+    def _norm(self, pv, name, c):
+        self.w[name + ".weight"] = self._dev(pv.norm_weight(name + ".weight", c), F32)
+        self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
+
+    def _resnet(self, pv, p, cin, cout, temb_acc):
+        T = self.cfg.time_embed_dim
+        self._norm(pv, p + ".norm1", cin)
+        self._conv(pv, p + ".conv1", cin, cout, 3)
+        tw = pv.weight(p + ".time_emb_proj.weight", (cout, T), T, 1.0)
+        tb = pv.bias(p + ".time_emb_proj.bias", cout)
+        self.temb_slices[p] = (temb_acc["n"], cout)
+        temb_acc["w"].append(tw)
+        temb_acc["b"].append(tb)
+        temb_acc["n"] += cout
+        self._norm(pv, p + ".norm2", cout)
+        self._conv(pv, p + ".conv2", cout, cout, 3, gain=0.5)
+        if cin != cout:
+            # 1x1 shortcut as a plain GEMM on [tokens, cin]
+            w = pv.weight(p + ".conv_shortcut.weight", (cout, cin, 1, 1), cin, 1.0)
+            self.w[p + ".conv_shortcut.weight"] = self._dev(w.reshape(cout, cin), F16)
+            self.w[p + ".conv_shortcut.bias"] = self._dev(pv.bias(p + ".conv_shortcut.bias", cout), F32)
+
+    def _transformer(self, pv, p, c, depth, ctx_acc):
+        X = self.cfg.cross_dim
+        self._norm(pv, p + ".norm", c)
+        self._linear(pv, p + ".proj_in", c, c)
+        for d in range(depth):
+            b = f"{p}.transformer_blocks.{d}"
+            self._norm(pv, b + ".norm1", c)
+            q = self._linear(pv, b + ".attn1.to_q", c, c, bias=False, keep_host=True)
+            k = self._linear(pv, b + ".attn1.to_k", c, c, bias=False, keep_host=True)
+            self.w[b + ".attn1.qk"] = self._dev(torch.cat([q, k], 0), F16)
+            self._linear(pv, b + ".attn1.to_v", c, c, bias=False)
+            self._linear(pv, b + ".attn1.to_out.0", c, c, gain=0.5)
+            self._norm(pv, b + ".norm2", c)
+            self._linear(pv, b + ".attn2.to_q", c, c, bias=False)
+            ck = self._linear(pv, b + ".attn2.to_k", X, c, bias=False, keep_host=True)
+            cv = self._linear(pv, b + ".attn2.to_v", X, c, bias=False, keep_host=True)
+            self.ctx_slices[b] = (ctx_acc["n"], c)
+            ctx_acc["k"].append(ck)
+            ctx_acc["v"].append(cv)
+            ctx_acc["n"] += c
+            self._linear(pv, b + ".attn2.to_out.0", c, c, gain=0.5)
+            self._norm(pv, b + ".norm3", c)
+            self._linear(pv, b + ".ff.net.0.proj", c, 8 * c)
+            self._linear(pv, b + ".ff.net.2", 4 * c, c, gain=0.5)
+        self._linear(pv, p + ".proj_out", c, c, gain=0.5)
+
+    def skip_channels(self) -> List[int]:
+        ch = self.cfg.block_channels
+        skips = [ch[0]]
+        for bi, c in enumerate(ch):
+            skips += [c] * self.cfg.layers_per_block
+            if bi < len(ch) - 1:
+                skips.append(c)
+        return skips
+
+    def up_plan(self):
+        skips = self.skip_channels()
+        plan, hidden = [], self.cfg.block_channels[-1]
+        for c in reversed(self.cfg.block_channels):
+            cins = []
+            for _ in range(self.cfg.layers_per_block + 1):
+                cins.append((hidden, skips.pop()))
+                hidden = c
+            plan.append((c, cins))
+        return plan
+
+    def _load(self, pv):
+        cfg = self.cfg
+        ch, T = cfg.block_channels, cfg.time_embed_dim
+        temb_acc = {"w": [], "b": [], "n": 0}
+        ctx_acc = {"k": [], "v": [], "n": 0}
+        self._conv(pv, "conv_in", cfg.in_channels, ch[0], 3)
+        self._linear(pv, "time_embedding.linear_1", ch[0], T)
+        self._linear(pv, "time_embedding.linear_2", T, T)
+        self._linear(pv, "add_embedding.linear_1", cfg.add_in_dim, T)
+        self._linear(pv, "add_embedding.linear_2", T, T)
+        prev = ch[0]
+        for bi, c in enumerate(ch):
+            for li in range(cfg.layers_per_block):
+                self._resnet(pv, f"down_blocks.{bi}.resnets.{li}", prev, c, temb_acc)
+                if cfg.transformer_depth[bi]:
+                    self._transformer(pv, f"down_blocks.{bi}.attentions.{li}", c, cfg.transformer_depth[bi], ctx_acc)
+                prev = c
+            if bi < len(ch) - 1:
+                self._conv(pv, f"down_blocks.{bi}.downsamplers.0.conv", c, c, 3)
+        c = ch[-1]
+        self._resnet(pv, "mid_block.resnets.0", c, c, temb_acc)
+        self._transformer(pv, "mid_block.attentions.0", c, cfg.transformer_depth[-1], ctx_acc)
+        self._resnet(pv, "mid_block.resnets.1", c, c, temb_acc)
+        depths = list(reversed(cfg.transformer_depth))
+        for ui, (c, cins) in enumerate(self.up_plan()):
+            for li, (hid, skip) in enumerate(cins):
+                self._resnet(pv, f"up_blocks.{ui}.resnets.{li}", hid + skip, c, temb_acc)
+                if depths[ui]:
+                    self._transformer(pv, f"up_blocks.{ui}.attentions.{li}", c, depths[ui], ctx_acc)
+            if ui < len(ch) - 1:
+                self._conv(pv, f"up_blocks.{ui}.upsamplers.0.conv", c, c, 3)
+        self._norm(pv, "conv_norm_out", ch[0])
+        self._conv(pv, "conv_out", ch[0], cfg.out_channels, 3, gain=0.5)
+        # fused projections
+        self.w["temb_proj.weight"] = self._dev(torch.cat(temb_acc["w"], 0), F16)
+        self.w["temb_proj.bias"] = self._dev(torch.cat(temb_acc["b"], 0), F32)
+        self.w["ctx_k.weight"] = self._dev(torch.cat(ctx_acc["k"], 0), F16)
+        self.w["ctx_v.weight"] = self._dev(torch.cat(ctx_acc["v"], 0), F16)
+        self.n_temb, self.n_ctx = temb_acc["n"], ctx_acc["n"]
+
+    def weight_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------ program -----------
+    def build(self, B: int, L: int) -> "UNetProgram":
+        return UNetProgram(self, B, L)
+
+
+class UNetProgram:
+    """One recorded forward for a fixed (batch, latent side).  Inputs are device buffers the
+    caller fills (torch copies on the launch stream); ``run`` replays the launches."""
+
+    def __init__(self, net: NativeUNet, B: int, L: int):
+        cfg = net.cfg
+        self.net, self.B, self.L = net, B, L
+        dev = net.device
+        self.arena = Arena(dev)
+        self.em = Emitter(self.arena)
+        T = cfg.time_embed_dim
+        # ---- inputs / outputs (persistent) ----
+        self.x_in = torch.zeros(B, cfg.in_channels, L, L, dtype=F16, device=dev)
+        self.tvals = torch.zeros(B, 1, dtype=F32, device=dev)
+        self.time_ids = torch.zeros(B, 6, dtype=F32, device=dev)
+        self.ctx = torch.zeros(B, CTX_PAD, cfg.cross_dim, dtype=F16, device=dev)     # rows 77..79 stay zero
+        self.text_embeds = torch.zeros(B, cfg.pooled_dim, dtype=F16, device=dev)
+        self.eps = torch.zeros(B, cfg.out_channels, L, L, dtype=F16, device=dev)
+        # ---- conditioning-program outputs (persistent) ----
+        self.aug = torch.zeros(B, T, dtype=F16, device=dev)
+        self.ctx_k = torch.zeros(B * CTX_PAD, net.n_ctx, dtype=F16, device=dev)
+        self.ctx_vt = torch.zeros(net.n_ctx, B * CTX_PAD, dtype=F16, device=dev)
+        self.prog_cond = Program("unet-cond")
+        self.prog_step = Program("unet-step")
+        with self.prog_cond.record():
+            self._emit_cond()
+        with self.prog_step.record():
+            self._emit_step()
+        self.taps: Dict[str, torch.Tensor] = {}
+
+    # ---- helpers ------------------------------------------------------------------------
+    def _conv(self, x, name, B, H, W, cin, cout, *, stride=1, ups=0, rowvec=None, ld_rowvec=None,
+              residual=None, out=None, flags=0, k=3, pad=1):
+        em, w = self.em, self.net.w
+        he, we = H << ups, W << ups
+        ho, wo = (he + 2 * pad - k) // stride + 1, (we + 2 * pad - k) // stride + 1
+        cin_p, cout_p = _pad(cin, 8), _pad(cout, 4)
+        if out is None:
+            out = self.arena.alloc((B, ho, wo, cout_p), F32 if flags & lib.GEMM_OUT_F32 else F16)
+        em.gemm(x, w[name + ".weight"], out, M=B * ho * wo, bias=w[name + ".bias"], residual=residual,
+                rowvec=rowvec, rows_per_batch=ho * wo, ld_rowvec=ld_rowvec, flags=flags,
+                conv=dict(Hin=H, Win=W, Cin=cin_p, Hout=ho, Wout=wo, KH=k, KW=k, stride=stride, pad=pad,
+                          ups=ups, ldx=cin_p))
+        return out, ho, wo
+
+    def _resnet(self, x, p, B, H, W, cin, cout):
+        em, w, ar, g = self.em, self.net.w, self.arena, self.net.cfg.norm_groups
+        n1 = ar.alloc((B, H, W, cin))
+        em.groupnorm(x, n1, w[p + ".norm1.weight"], w[p + ".norm1.bias"], B=B, HW=H * W, C_=cin, eps=1e-5,
+                     silu=True, groups=g)
+        off, _ = self.net.temb_slices[p]
+        rv = self.temb_all[:, off:]                     # column slice: pointer offset + ld = n_temb
+        h, _, _ = self._conv(n1, p + ".conv1", B, H, W, cin, cout, rowvec=rv, ld_rowvec=self.net.n_temb)
+        ar.release(n1)
+        n2 = ar.alloc((B, H, W, cout))
+        em.groupnorm(h, n2, w[p + ".norm2.weight"], w[p + ".norm2.bias"], B=B, HW=H * W, C_=cout, eps=1e-5,
+                     silu=True, groups=g)
+        ar.release(h)
+        if cin != cout:
+            xs = ar.alloc((B, H, W, cout))
+            em.gemm(x, w[p + ".conv_shortcut.weight"], xs, M=B * H * W, bias=w[p + ".conv_shortcut.bias"])
+        else:
+            xs = x
+        out, _, _ = self._conv(n2, p + ".conv2", B, H, W, cout, cout, residual=xs)
+        ar.release(n2)
+        if xs is not x:
+            ar.release(xs)
+        return out
+
+    def _transformer(self, x, p, B, H, W, c, depth):
+        em, w, ar = self.em, self.net.w, self.arena
+        M, S, heads = B * H * W, H * W, c // 64
+        n = ar.alloc((M, c))
+        em.groupnorm(x, n, w[p + ".norm.weight"], w[p + ".norm.bias"], B=B, HW=S, C_=c, eps=1e-6, silu=False,
+                     groups=self.net.cfg.norm_groups)
+        h = ar.alloc((M, c))
+        em.gemm(n, w[p + ".proj_in.weight"], h, M=M, bias=w[p + ".proj_in.bias"])
+        ar.release(n)
+        for d in range(depth):
+            b = f"{p}.transformer_blocks.{d}"
+            # --- self attention ---
+            ln = ar.alloc((M, c))
+            em.layernorm(h, ln, w[b + ".norm1.weight"], w[b + ".norm1.bias"], M=M, C_=c)
+            qk = ar.alloc((M, 2 * c))
+            em.gemm(ln, w[b + ".attn1.qk"], qk, M=M)
+            vt = ar.alloc((c, M))
+            em.gemm(w[b + ".attn1.to_v.weight"], ln, vt, M=c)            # V^T = W_v . X^T
+            ar.release(ln)
+            a = ar.alloc((M, c))
+            em.attention(qk.data_ptr(), qk.data_ptr() + c * 2, vt.data_ptr(), a, B=B, H=heads, Sq=S, Skv=S,
+                         valid=S, ldq=2 * c, ldk=2 * c, ldvt=M, ldo=c)
+            ar.release(qk)
+            ar.release(vt)
+            em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h)
+            ar.release(a)
+            # --- cross attention (K / V^T of the text context come from the conditioning program) ---
+            ln = ar.alloc((M, c))
+            em.layernorm(h, ln, w[b + ".norm2.weight"], w[b + ".norm2.bias"], M=M, C_=c)
+            q = ar.alloc((M, c))
+            em.gemm(ln, w[b + ".attn2.to_q.weight"], q, M=M)
+            ar.release(ln)
+            off, _ = self.net.ctx_slices[b]
+            a = ar.alloc((M, c))
+            em.attention(q.data_ptr(), self.ctx_k.data_ptr() + off * 2,
+                         self.ctx_vt.data_ptr() + off * (B * CTX_PAD) * 2, a, B=B, H=heads, Sq=S, Skv=CTX_PAD,
+                         valid=CTX_TOKENS, ldq=c, ldk=self.net.n_ctx, ldvt=B * CTX_PAD, ldo=c)
+            ar.release(q)
+            em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h)
+            ar.release(a)
+            # --- GEGLU feed-forward ---
+            ln = ar.alloc((M, c))
+            em.layernorm(h, ln, w[b + ".norm3.weight"], w[b + ".norm3.bias"], M=M, C_=c)
+            ff = ar.alloc((M, 4 * c))
+            em.gemm(ln, w[b + ".ff.net.0.proj.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj.bias"],
+                    flags=lib.GEMM_GEGLU)
+            ar.release(ln)
+            em.gemm(ff, w[b + ".ff.net.2.weight"], h, M=M, bias=w[b + ".ff.net.2.bias"], residual=h)
+            ar.release(ff)
+        out = ar.alloc((B, H, W, c))
+        em.gemm(h, w[p + ".proj_out.weight"], out, M=M, bias=w[p + ".proj_out.bias"], residual=x)
+        ar.release(h)
+        return out
+
+    # ---- conditioning program: everything that depends on (text context, pooled, time ids) only
+    def _emit_cond(self):
+        cfg, em, w, ar, B = self.net.cfg, self.em, self.net.w, self.arena, self.B
+        add_in = ar.alloc((B, cfg.add_in_dim))
+        em.copy_cols(self.text_embeds, add_in, rows=B, cols=cfg.pooled_dim, ld_src=cfg.pooled_dim,
+                     ld_dst=cfg.add_in_dim, dst_off=0)
+        api.lb_sinusoid_f16(self.time_ids.data_ptr(), B, 6, 6, cfg.add_time_dim, add_in.data_ptr(), cfg.add_in_dim,
+                            cfg.pooled_dim, _stream())
+        a1 = ar.alloc((B, cfg.time_embed_dim))
+        em.gemm(add_in, w["add_embedding.linear_1.weight"], a1, M=B, bias=w["add_embedding.linear_1.bias"],
+                flags=lib.GEMM_SILU)
+        em.gemm(a1, w["add_embedding.linear_2.weight"], self.aug, M=B, bias=w["add_embedding.linear_2.bias"])
+        ar.release(add_in)
+        ar.release(a1)
+        ctx2d = self.ctx.view(B * CTX_PAD, cfg.cross_dim)
+        em.gemm(ctx2d, w["ctx_k.weight"], self.ctx_k, M=B * CTX_PAD)
+        em.gemm(w["ctx_v.weight"], ctx2d, self.ctx_vt, M=self.net.n_ctx)
+
+    # ---- step program: depends on the latent and the timestep
+    def _emit_step(self):
+        net, cfg, em, w, ar, B, L = self.net, self.net.cfg, self.em, self.net.w, self.arena, self.B, self.L
+        ch, T = cfg.block_channels, cfg.time_embed_dim
+        # time embedding: silu(temb + aug) feeds every resnet's projection -> one fused GEMM
+        tsin = ar.alloc((B, ch[0]))
+        api.lb_sinusoid_f16(self.tvals.data_ptr(), B, 1, 1, ch[0], tsin.data_ptr(), ch[0], 0, _stream())
+        t1 = ar.alloc((B, T))
+        em.gemm(tsin, w["time_embedding.linear_1.weight"], t1, M=B, bias=w["time_embedding.linear_1.bias"],
+                flags=lib.GEMM_SILU)
+        emb = ar.alloc((B, T))
+        em.gemm(t1, w["time_embedding.linear_2.weight"], emb, M=B, bias=w["time_embedding.linear_2.bias"],
+                residual=self.aug, flags=lib.GEMM_SILU)
+        self.temb_all = ar.alloc((B, net.n_temb))
+        em.gemm(emb, w["temb_proj.weight"], self.temb_all, M=B, bias=w["temb_proj.bias"])
+        ar.release(tsin)
+        ar.release(t1)
+        ar.release(emb)
+        # input: NCHW latent -> NHWC (channels padded to 8)
+        cin_p = _pad(cfg.in_channels, 8)
+        x8 = ar.alloc((B, L, L, cin_p))
+        api.lb_nchw_to_nhwc_f16(self.x_in.data_ptr(), x8.data_ptr(), B, cfg.in_channels, L * L, cin_p, 1.0, _stream())
+        h, _, _ = self._conv(x8, "conv_in", B, L, L, cfg.in_channels, ch[0])
+        ar.release(x8)
+        skips = [(h, ch[0])]
+        side, prev = L, ch[0]
+        for bi, c in enumerate(ch):
+            for li in range(cfg.layers_per_block):
+                nxt = self._resnet(h, f"down_blocks.{bi}.resnets.{li}", B, side, side, prev, c)
+                if not any(h is s for s, _ in skips):
+                    ar.release(h)
+                h = nxt
+                if cfg.transformer_depth[bi]:
+                    nxt = self._transformer(h, f"down_blocks.{bi}.attentions.{li}", B, side, side, c,
+                                            cfg.transformer_depth[bi])
+                    ar.release(h)
+                    h = nxt
+                skips.append((h, c))
+                prev = c
+            if bi < len(ch) - 1:
+                h, side, _ = self._conv(h, f"down_blocks.{bi}.downsamplers.0.conv", B, side, side, c, c, stride=2)
+                skips.append((h, c))
+        c = ch[-1]
+        nxt = self._resnet(h, "mid_block.resnets.0", B, side, side, c, c)     # h is a skip: not released
+        h = nxt
+        nxt = self._transformer(h, "mid_block.attentions.0", B, side, side, c, cfg.transformer_depth[-1])
+        ar.release(h)
+        h = nxt
+        nxt = self._resnet(h, "mid_block.resnets.1", B, side, side, c, c)
+        ar.release(h)
+        h = nxt
+        depths = list(reversed(cfg.transformer_depth))
+        for ui, (c, cins) in enumerate(net.up_plan()):
+            for li, (hid, sc) in enumerate(cins):
+                skip, sch = skips.pop()
+                assert sch == sc
+                M = B * side * side
+                cat = ar.alloc((B, side, side, hid + sc))
+                em.copy_cols(h, cat, rows=M, cols=hid, ld_src=hid, ld_dst=hid + sc, dst_off=0)
+                em.copy_cols(skip, cat, rows=M, cols=sc, ld_src=sc, ld_dst=hid + sc, dst_off=hid)
+                ar.release(h)
+                ar.release(skip)
+                h = self._resnet(cat, f"up_blocks.{ui}.resnets.{li}", B, side, side, hid + sc, c)
+                ar.release(cat)
+                if depths[ui]:
+                    nxt = self._transformer(h, f"up_blocks.{ui}.attentions.{li}", B, side, side, c, depths[ui])
+                    ar.release(h)
+                    h = nxt
+            if ui < len(ch) - 1:
+                nxt, side, _ = self._conv(h, f"up_blocks.{ui}.upsamplers.0.conv", B, side, side, c, c, ups=1)
+                ar.release(h)
+                h = nxt
+        n = ar.alloc((B, side, side, ch[0]))
+        em.groupnorm(h, n, w["conv_norm_out.weight"], w["conv_norm_out.bias"], B=B, HW=side * side, C_=ch[0],
+                     eps=1e-5, silu=True, groups=cfg.norm_groups)
+        ar.release(h)
+        o, _, _ = self._conv(n, "conv_out", B, side, side, ch[0], cfg.out_channels)
+        ar.release(n)
+        api.lb_nhwc_to_nchw_f16(o.data_ptr(), self.eps.data_ptr(), B, cfg.out_channels, L * L,
+                                _pad(cfg.out_channels, 4), _stream())
+        ar.release(o)
+
+    # ---- execution ------------------------------------------------------------------------
+    def set_conditioning(self, ctx: torch.Tensor, text_embeds: torch.Tensor, time_ids: torch.Tensor):
+        """ctx [B,77,X] fp16, text_embeds [B,P] fp16, time_ids [B,6] (any float dtype)."""
+        self.ctx[:, :CTX_TOKENS].copy_(ctx)
+        self.text_embeds.copy_(text_embeds)
+        self.time_ids.copy_(time_ids.to(F32))
+        self.prog_cond.launch()
+
+    def forward(self, x_in: torch.Tensor, tvals: torch.Tensor) -> torch.Tensor:
+        """x_in [B,4,L,L] fp16 (already scaled), tvals [B] -> eps [B,4,L,L] fp16 (program-owned buffer)."""
+        self.x_in.copy_(x_in)
+        self.tvals.copy_(tvals.reshape(-1, 1).to(F32))
+        self.prog_step.launch()
+        return self.eps
+
+    def enable_graphs(self):
+        self.prog_cond.instantiate()
+        self.prog_step.instantiate()

@@ -1,0 +1,237 @@
+"""Native SDXL VAE decoder (diffusers ``AutoencoderKL.decode`` + ``VaeImageProcessor.postprocess``,
+reached from /root/reference/latentblending/diffusers_holder.py:115-143) for gfx950.
+
+Precision plan (replaces the reference's "upcast the whole VAE to fp32 on every decode",
+diffusers_holder.py:129-139): the SDXL VAE overflows fp16 in its residual stream, not in its
+normalised activations.  So
+  * the residual stream and every conv output are kept in **fp32** (GEMM epilogue ``OUT_F32``),
+  * GroupNorm(+SiLU) reads fp32 and writes **fp16** (bounded after normalisation) — these are the
+    MFMA operands, accumulated in fp32,
+  * the two places where the raw stream itself feeds a contraction (1x1 shortcuts, upsampler
+    convs) down-scale by 2^-4 while casting to fp16 and multiply back in the epilogue (``alpha``).
+Net effect: fp16 MFMA rate (16x the fp32 rate on gfx950) with fp32 range where it matters.
+The mid-block attention (1 head, d = 512) is GEMM -> row softmax -> GEMM; its V bias is folded
+into the output projection bias at load time (softmax rows sum to 1).
+Output is quantised on device to uint8 NHWC frames.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+
+from ..hip import lib
+from ..hip.lib import api
+from .runtime import Arena, Emitter, Program, F16, F32, _stream
+from .unet import _pad
+
+STREAM_SCALE = 1.0 / 16.0
+
+
+@dataclass
+class VAEConfig:
+    latent_channels: int = 4
+    out_channels: int = 3
+    block_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_groups: int = 32
+    scaling_factor: float = 0.13025
+    force_upcast: bool = True
+
+    @property
+    def scale_factor(self) -> int:
+        return 2 ** (len(self.block_channels) - 1)
+
+
+class NativeVAEDecoder:
+    def __init__(self, cfg: VAEConfig, provider, device="cuda"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+        self._load(provider)
+
+    def _dev(self, t, dtype):
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def _conv(self, pv, name, cin, cout, k, gain=1.0):
+        w = pv.weight(name + ".weight", (cout, cin, k, k), cin * k * k, gain)
+        cin_p, cout_p = _pad(cin, 8), _pad(cout, 4)
+        packed = torch.zeros(cout_p, k, k, cin_p, dtype=torch.float32)
+        packed[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+        self.w[name + ".weight"] = self._dev(packed.reshape(cout_p, k * k * cin_p), F16)
+        b = torch.zeros(cout_p, dtype=torch.float32)
+        b[:cout] = pv.bias(name + ".bias", cout)
+        self.w[name + ".bias"] = self._dev(b, F32)
+
+    def _norm(self, pv, name, c):
+        self.w[name + ".weight"] = self._dev(pv.norm_weight(name + ".weight", c), F32)
+        self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
+
+    def _resnet(self, pv, p, cin, cout):
+        self._norm(pv, p + ".norm1", cin)
+        self._conv(pv, p + ".conv1", cin, cout, 3)
+        self._norm(pv, p + ".norm2", cout)
+        self._conv(pv, p + ".conv2", cout, cout, 3, gain=0.5)
+        if cin != cout:
+            w = pv.weight(p + ".conv_shortcut.weight", (cout, cin, 1, 1), cin, 1.0)
+            self.w[p + ".conv_shortcut.weight"] = self._dev(w.reshape(cout, cin), F16)
+            self.w[p + ".conv_shortcut.bias"] = self._dev(pv.bias(p + ".conv_shortcut.bias", cout), F32)
+
+    def _load(self, pv):
+        cfg = self.cfg
+        rev = list(reversed(cfg.block_channels))
+        top = rev[0]
+        self._conv(pv, "post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+        self._conv(pv, "decoder.conv_in", cfg.latent_channels, top, 3)
+        self._resnet(pv, "decoder.mid_block.resnets.0", top, top)
+        a = "decoder.mid_block.attentions.0"
+        self._norm(pv, a + ".group_norm", top)
+        for nm in ("to_q", "to_k"):
+            self.w[f"{a}.{nm}.weight"] = self._dev(pv.weight(f"{a}.{nm}.weight", (top, top), top), F16)
+            self.w[f"{a}.{nm}.bias"] = self._dev(pv.bias(f"{a}.{nm}.bias", top), F32)
+        wv = pv.weight(a + ".to_v.weight", (top, top), top)
+        bv = pv.bias(a + ".to_v.bias", top)
+        wo = pv.weight(a + ".to_out.0.weight", (top, top), top, 0.5)
+        bo = pv.bias(a + ".to_out.0.bias", top)
+        self.w[a + ".to_v.weight"] = self._dev(wv, F16)
+        self.w[a + ".to_out.0.weight"] = self._dev(wo, F16)
+        self.w[a + ".to_out.0.bias"] = self._dev(bo + wo.half().float() @ bv, F32)   # V bias folded
+        self._resnet(pv, "decoder.mid_block.resnets.1", top, top)
+        prev = top
+        for ui, c in enumerate(rev):
+            for li in range(cfg.layers_per_block + 1):
+                self._resnet(pv, f"decoder.up_blocks.{ui}.resnets.{li}", prev, c)
+                prev = c
+            if ui < len(rev) - 1:
+                self._conv(pv, f"decoder.up_blocks.{ui}.upsamplers.0.conv", c, c, 3)
+        self._norm(pv, "decoder.conv_norm_out", rev[-1])
+        self._conv(pv, "decoder.conv_out", rev[-1], cfg.out_channels, 3, gain=0.5)
+
+    def build(self, B: int, L: int) -> "VAEProgram":
+        return VAEProgram(self, B, L)
+
+
+class VAEProgram:
+    def __init__(self, net: NativeVAEDecoder, B: int, L: int):
+        cfg = net.cfg
+        self.net, self.B, self.L = net, B, L
+        dev = net.device
+        self.arena = Arena(dev)
+        self.em = Emitter(self.arena)
+        S = L * cfg.scale_factor
+        self.z_in = torch.zeros(B, cfg.latent_channels, L, L, dtype=F16, device=dev)
+        self.frames = torch.zeros(B, S, S, 3, dtype=torch.uint8, device=dev)
+        self.image_f32 = torch.zeros(B, S, S, _pad(cfg.out_channels, 4), dtype=F32, device=dev)
+        self._pq = torch.zeros(B, L, L, _pad(cfg.latent_channels, 8), dtype=F16, device=dev)  # pad channels stay 0
+        self.prog = Program("vae-decode")
+        with self.prog.record():
+            self._emit()
+
+    def _conv(self, x, name, B, H, W, cin, cout, *, ups=0, residual=None, alpha=1.0, out=None):
+        w = self.net.w
+        he, we = H << ups, W << ups
+        cin_p, cout_p = _pad(cin, 8), _pad(cout, 4)
+        if out is None:
+            out = self.arena.alloc((B, he, we, cout_p), F32)
+        flags = lib.GEMM_OUT_F32 | (lib.GEMM_RES_F32 if residual is not None else 0)
+        self.em.gemm(x, w[name + ".weight"], out, M=B * he * we, bias=w[name + ".bias"], residual=residual,
+                     flags=flags, alpha=alpha,
+                     conv=dict(Hin=H, Win=W, Cin=cin_p, Hout=he, Wout=we, KH=3, KW=3, stride=1, pad=1, ups=ups,
+                               ldx=cin_p))
+        return out
+
+    def _resnet(self, x, p, B, H, W, cin, cout):
+        em, w, ar, g = self.em, self.net.w, self.arena, self.net.cfg.norm_groups
+        n1 = ar.alloc((B, H, W, cin))
+        em.groupnorm(x, n1, w[p + ".norm1.weight"], w[p + ".norm1.bias"], B=B, HW=H * W, C_=cin, eps=1e-6,
+                     silu=True, groups=g)
+        h = self._conv(n1, p + ".conv1", B, H, W, cin, cout)
+        ar.release(n1)
+        n2 = ar.alloc((B, H, W, cout))
+        em.groupnorm(h, n2, w[p + ".norm2.weight"], w[p + ".norm2.bias"], B=B, HW=H * W, C_=cout, eps=1e-6,
+                     silu=True, groups=g)
+        ar.release(h)
+        if cin != cout:
+            x16 = ar.alloc((B, H, W, cin))
+            api.lb_cast_f32_to_f16(x.data_ptr(), x16.data_ptr(), x.numel(), STREAM_SCALE, _stream())
+            xs = ar.alloc((B, H, W, cout), F32)
+            em.gemm(x16, w[p + ".conv_shortcut.weight"], xs, M=B * H * W, bias=w[p + ".conv_shortcut.bias"],
+                    flags=lib.GEMM_OUT_F32, alpha=1.0 / STREAM_SCALE)
+            ar.release(x16)
+        else:
+            xs = x
+        out = self._conv(n2, p + ".conv2", B, H, W, cout, cout, residual=xs)
+        ar.release(n2)
+        if xs is not x:
+            ar.release(xs)
+        return out
+
+    def _mid_attention(self, h, B, H, W, c):
+        em, w, ar = self.em, self.net.w, self.arena
+        a = "decoder.mid_block.attentions.0"
+        S = H * W
+        n = ar.alloc((B * S, c))
+        em.groupnorm(h, n, w[a + ".group_norm.weight"], w[a + ".group_norm.bias"], B=B, HW=S, C_=c, eps=1e-6,
+                     silu=False, groups=self.net.cfg.norm_groups)
+        q, k = ar.alloc((B * S, c)), ar.alloc((B * S, c))
+        em.gemm(n, w[a + ".to_q.weight"], q, M=B * S, bias=w[a + ".to_q.bias"])
+        em.gemm(n, w[a + ".to_k.weight"], k, M=B * S, bias=w[a + ".to_k.bias"])
+        vt = ar.alloc((c, B * S))
+        em.gemm(w[a + ".to_v.weight"], n, vt, M=c)                      # V^T (bias folded into to_out)
+        ar.release(n)
+        o = ar.alloc((B * S, c))
+        scores = ar.alloc((S, S))
+        for b in range(B):
+            qb, kb, ob = q[b * S:(b + 1) * S], k[b * S:(b + 1) * S], o[b * S:(b + 1) * S]
+            em.gemm(qb, kb, scores, M=S, alpha=float(c) ** -0.5)
+            api.lb_softmax_rows_f16(scores.data_ptr(), S, S, S, 1.0, _stream())
+            em.gemm(scores, vt[:, b * S:(b + 1) * S], ob, M=S, lda=S)    # W = V^T slice [c, S], ldw = B*S
+        ar.release(scores); ar.release(q); ar.release(k); ar.release(vt)
+        em.gemm(o, w[a + ".to_out.0.weight"], h, M=B * S, bias=w[a + ".to_out.0.bias"], residual=h,
+                flags=lib.GEMM_OUT_F32 | lib.GEMM_RES_F32)
+        ar.release(o)
+        return h
+
+    def _emit(self):
+        net, cfg, em, w, ar, B, L = self.net, self.net.cfg, self.em, self.net.w, self.arena, self.B, self.L
+        rev = list(reversed(cfg.block_channels))
+        top, lc = rev[0], cfg.latent_channels
+        lc_p = _pad(lc, 8)
+        z8 = ar.alloc((B, L, L, lc_p))
+        api.lb_nchw_to_nhwc_f16(self.z_in.data_ptr(), z8.data_ptr(), B, lc, L * L, lc_p, 1.0 / cfg.scaling_factor,
+                                _stream())
+        # post_quant_conv (1x1) writes the first `lc` channels of a zero-padded buffer
+        em.gemm(z8, w["post_quant_conv.weight"], self._pq, M=B * L * L, bias=w["post_quant_conv.bias"], ldc=lc_p)
+        ar.release(z8)
+        h = self._conv(self._pq, "decoder.conv_in", B, L, L, lc, top)
+        nxt = self._resnet(h, "decoder.mid_block.resnets.0", B, L, L, top, top); ar.release(h); h = nxt
+        h = self._mid_attention(h, B, L, L, top)
+        nxt = self._resnet(h, "decoder.mid_block.resnets.1", B, L, L, top, top); ar.release(h); h = nxt
+        side, prev = L, top
+        for ui, c in enumerate(rev):
+            for li in range(cfg.layers_per_block + 1):
+                nxt = self._resnet(h, f"decoder.up_blocks.{ui}.resnets.{li}", B, side, side, prev, c)
+                ar.release(h); h = nxt
+                prev = c
+            if ui < len(rev) - 1:
+                h16 = ar.alloc((B, side, side, c))
+                api.lb_cast_f32_to_f16(h.data_ptr(), h16.data_ptr(), h.numel(), STREAM_SCALE, _stream())
+                ar.release(h)
+                h = self._conv(h16, f"decoder.up_blocks.{ui}.upsamplers.0.conv", B, side, side, c, c, ups=1,
+                               alpha=1.0 / STREAM_SCALE)
+                ar.release(h16)
+                side *= 2
+        n = ar.alloc((B, side, side, rev[-1]))
+        em.groupnorm(h, n, w["decoder.conv_norm_out.weight"], w["decoder.conv_norm_out.bias"], B=B, HW=side * side,
+                     C_=rev[-1], eps=1e-6, silu=True, groups=cfg.norm_groups)
+        ar.release(h)
+        self._conv(n, "decoder.conv_out", B, side, side, rev[-1], cfg.out_channels, out=self.image_f32)
+        ar.release(n)
+        api.lb_postprocess_u8(self.image_f32.data_ptr(), self.frames.data_ptr(), B * side * side,
+                              _pad(cfg.out_channels, 4), 1, _stream())
+
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z [B,4,L,L] fp16 final latents (NOT yet divided by the scaling factor) -> uint8 [B,8L,8L,3]."""
+        self.z_in.copy_(z)
+        self.prog.launch()
+        return self.frames

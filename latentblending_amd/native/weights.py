@@ -1,0 +1,85 @@
+"""Parameter providers for the native SDXL modules.
+
+The model builders walk their architecture and ask a provider for every parameter by its HF
+diffusers state-dict name (``down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight``,
+``decoder.up_blocks.2.resnets.0.conv1.weight`` ...), so the same walk serves
+
+* ``DictProvider``      — a state dict: a real checkpoint's tensors (``from_safetensors``) or the
+  seeded weights a test shares with the CPU oracle;
+* ``SyntheticProvider`` — seeded random weights of the right shapes and scales, generated on the
+  fly (no checkpoint on disk and no network here; ``bench.py`` says ``"data": "synthetic"``).
+  Init: W ~ N(0, gain^2 / fan_in), b ~ N(0, 0.02^2), norm gamma ~ N(1, 0.05^2); residual-branch
+  output projections use gain 0.5 so that 70 stacked transformer blocks stay tame in fp16.
+  Values are rounded to fp16 so every consumer (fp16 device path, fp32 CPU oracle) sees
+  bit-identical parameters.  Seeds depend only on (name, seed): order independent.
+"""
+from __future__ import annotations
+
+import math
+import os
+import zlib
+from typing import Dict, Optional, Sequence
+
+import torch
+
+
+def _seeded(name: str, shape: Sequence[int], std: float, seed: int, mean: float = 0.0) -> torch.Tensor:
+    g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32) * std + mean
+
+
+class SyntheticProvider:
+    def __init__(self, seed: int = 0):
+        self.seed = seed
+
+    def weight(self, name: str, shape: Sequence[int], fan_in: int, gain: float = 1.0) -> torch.Tensor:
+        return _seeded(name, shape, gain / math.sqrt(fan_in), self.seed).half().float()
+
+    def bias(self, name: str, n: int) -> torch.Tensor:
+        return _seeded(name, (n,), 0.02, self.seed).half().float()
+
+    def norm_weight(self, name: str, n: int) -> torch.Tensor:
+        return _seeded(name, (n,), 0.05, self.seed, mean=1.0).half().float()
+
+    def positive(self, name: str, n: int) -> torch.Tensor:        # LPIPS lin layers (non-negative)
+        return (_seeded(name, (n,), 1.0, self.seed).abs() / n).half().float()
+
+
+class DictProvider:
+    """State dict lookup; shapes are checked, scales/gains ignored."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], prefix: str = ""):
+        self.state, self.prefix = state, prefix
+
+    def _get(self, name: str, shape) -> torch.Tensor:
+        key = self.prefix + name
+        if key not in self.state:
+            raise KeyError(f"parameter '{key}' missing from the state dict")
+        t = self.state[key]
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"parameter '{key}': expected shape {tuple(shape)}, found {tuple(t.shape)}")
+        return t.detach().to(torch.float32)
+
+    def weight(self, name, shape, fan_in=0, gain=1.0):
+        return self._get(name, shape)
+
+    def bias(self, name, n):
+        return self._get(name, (n,))
+
+    def norm_weight(self, name, n):
+        return self._get(name, (n,))
+
+    def positive(self, name, n):
+        t = self.state[self.prefix + name]
+        return t.detach().to(torch.float32).reshape(n)
+
+
+def from_safetensors(path: str, prefix: str = "") -> DictProvider:
+    """HF-layout ``*.safetensors`` file or directory (e.g. ``unet/diffusion_pytorch_model.fp16.safetensors``)."""
+    from safetensors.torch import load_file
+    files = [path] if os.path.isfile(path) else sorted(
+        os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors"))
+    state: Dict[str, torch.Tensor] = {}
+    for f in files:
+        state.update(load_file(f))
+    return DictProvider(state, prefix)

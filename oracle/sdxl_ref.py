@@ -571,7 +571,7 @@ def lpips_distance(w: Dict[str, Tensor], a: Tensor, b: Tensor) -> Tensor:
 
 class OracleLPIPS:
     def __init__(self, seed: int = 7):
-        self.w = make_weights(lpips_spec(), seed, round_fp16=False)
+        self.w = make_weights(lpips_spec(), seed, round_fp16=True)
 
     def cuda(self, *_a, **_k):
         return self
