@@ -158,6 +158,8 @@ int lb_program_run(void* prog, void* stream);                        /* eager re
 int lb_program_run_range(void* prog, int begin, int end, void* stream);
 int lb_program_instantiate(void* prog);                              /* capture into a hipGraph */
 int lb_program_launch(void* prog, void* stream);                     /* graph launch (or eager) */
+/* eager replay with hipEvents between ops; ms_out[num_ops]; synchronises (measurement only) */
+int lb_program_time_ops(void* prog, void* stream, float* ms_out);
 
 #ifdef __cplusplus
 }

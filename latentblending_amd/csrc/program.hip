@@ -121,3 +121,27 @@ extern "C" int lb_copy_d2d(void* dst, const void* src, long bytes, void* stream)
     LB_REQUIRE(dst && src && bytes > 0, "lb_copy_d2d: arguments");
     LB_DISPATCH("lb_copy_d2d", copy_impl(dst, src, bytes, s));
 }
+
+// Per-op device time of one eager replay: N+1 hipEvents on `stream`, ms_out[i] = time from the
+// event before op i to the event after it (kernel time + the launch boundary it really pays).
+// Used by bench.py for the live roofline numbers; synchronises, so never call it while recording.
+extern "C" int lb_program_time_ops(void* prog, void* stream_, float* ms_out) {
+    LbProgram* p = (LbProgram*)prog;
+    hipStream_t stream = (hipStream_t)stream_;
+    LB_REQUIRE(p && ms_out && !lb_recording(), "lb_program_time_ops: arguments");
+    const int n = (int)p->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    hipEventRecord(ev[0], stream);
+    int rc = 0;
+    for (int i = 0; i < n && rc == 0; ++i) {
+        rc = p->ops[i].fn(stream);
+        hipEventRecord(ev[i + 1], stream);
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (rc == 0 && e != hipSuccess) { lb_set_error("lb_program_time_ops", e); rc = (int)e; }
+    if (rc == 0)
+        for (int i = 0; i < n; ++i) hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+    for (auto& x : ev) hipEventDestroy(x);
+    return rc;
+}

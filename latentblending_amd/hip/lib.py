@@ -89,6 +89,7 @@ SIGNATURES = {
     "lb_program_run_range": (_i, [_vp, _i, _i, _vp]),
     "lb_program_instantiate": (_i, [_vp]),
     "lb_program_launch": (_i, [_vp, _vp]),
+    "lb_program_time_ops": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",

@@ -105,6 +105,13 @@ class Program:
     def launch(self, stream: Optional[int] = None) -> None:
         api.lb_program_launch(self.handle, stream if stream is not None else _stream())
 
+    def time_ops(self, stream: Optional[int] = None) -> List[float]:
+        """Eager replay with hipEvents between ops -> per-op milliseconds (synchronises)."""
+        n = self.num_ops
+        buf = (C.c_float * n)()
+        api.lb_program_time_ops(self.handle, stream if stream is not None else _stream(), buf)
+        return list(buf)
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -125,17 +132,30 @@ class Emitter:
         # one split-K slab region and one GroupNorm workspace shared by all ops of a program
         self.ws_gemm: Optional[torch.Tensor] = None
         self.ws_gn: Optional[torch.Tensor] = None
+        # algorithmic work of every emitted contraction, in emission order (bench.py roofline)
+        self.gemm_log: List[dict] = []
+        self.attn_log: List[dict] = []
+        self._retired: List[torch.Tensor] = []
 
     # -- workspaces -------------------------------------------------------------------------
-    def _gemm_ws(self, M: int, N: int) -> torch.Tensor:
+    def _gemm_ws(self, M: int, N: int) -> Optional[torch.Tensor]:
+        """Split-K slab region.  The launcher only splits grids of fewer than 160 64x64 tiles, so
+        larger problems get no workspace (and cannot split).  A grown workspace never replaces the
+        old one in already-recorded ops: superseded buffers are kept alive."""
+        if ((M + 63) // 64) * ((N + 63) // 64) >= 160:
+            return None
         need = api.lb_gemm_workspace_bytes(M, N) // 4
         if self.ws_gemm is None or self.ws_gemm.numel() < need:
+            if self.ws_gemm is not None:
+                self._retired.append(self.ws_gemm)
             self.ws_gemm = torch.empty(max(need, 1 << 22), dtype=F32, device=self.device)
         return self.ws_gemm
 
     def _gn_ws(self, B: int, groups: int) -> torch.Tensor:
         need = api.lb_groupnorm_workspace_bytes(B, groups) // 8
         if self.ws_gn is None or self.ws_gn.numel() < need:
+            if self.ws_gn is not None:
+                self._retired.append(self.ws_gn)
             self.ws_gn = torch.empty(need, dtype=torch.float64, device=self.device)
         return self.ws_gn
 
@@ -162,8 +182,10 @@ class Emitter:
             p.ld_rowvec, p.rows_per_batch = ld_rowvec if ld_rowvec is not None else N, rows_per_batch
         p.alpha, p.flags = alpha, flags
         if splitk and not (flags & lib.GEMM_GEGLU):
-            p.partial = self._gemm_ws(M, N).data_ptr()
+            p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())
+        self.gemm_log.append({"M": M, "N": N, "K": K, "flops": 2.0 * M * N * K, "conv": conv is not None,
+                              "bytes": 2.0 * (N * K + M * n_out) + (2.0 * M * K if conv is None else 0.0)})
         return out
 
     def groupnorm(self, x: torch.Tensor, out: torch.Tensor, gamma, beta, *, B: int, HW: int, C_: int,
@@ -186,6 +208,7 @@ class Emitter:
         p.ldq, p.ldk, p.ldvt, p.ldo = ldq, ldk, ldvt, ldo
         p.scale = 0.125
         api.lb_attn_fwd_d64(C.byref(p), _stream())
+        self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * 64})
         return out
 
     def copy_cols(self, src, dst, *, rows, cols, ld_src, ld_dst, dst_off):

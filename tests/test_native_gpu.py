@@ -204,3 +204,43 @@ def test_frontier_equals_sequential(results_log):
     d = np.stack([np.abs(np.asarray(a).astype(np.int32) - np.asarray(b).astype(np.int32)) for a, b in zip(i1, i4)])
     results_log["frontier_vs_sequential"] = {"mean_abs_u8": float(d.mean()), "max_abs_u8": int(d.max())}
     assert d.mean() <= 1.0
+
+
+def test_full_size_sdxl_unet_and_vae(results_log):
+    """BASELINE shapes: full SDXL UNet (2.57 B params) at B=1, 64x64 latent (512^2) and the full VAE
+    decoder, against the CPU fp32 oracle with the same seeded weights."""
+    n = native()
+    ucfg = R.UNetCfg(sample_size=64)
+    w = R.make_weights(R.unet_spec(ucfg), 0)
+    net = n.NativeUNet(n.UNetConfig(**dataclasses.asdict(ucfg)), n.DictProvider(w), DEV)
+    g = torch.Generator().manual_seed(123)
+    x = torch.randn(1, 4, 64, 64, generator=g).half()
+    ctx = torch.randn(1, 77, 2048, generator=g).half()
+    te = torch.randn(1, 1280, generator=g).half()
+    ids = torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]])
+    torch.set_num_threads(os.cpu_count() or 1)
+    ref = R.unet_forward(ucfg, w, x, torch.tensor(749.0), ctx, te, ids)
+    del w
+    prog = net.build(1, 64)
+    prog.set_conditioning(ctx.to(DEV), te.to(DEV), ids.to(DEV))
+    got = prog.forward(x.to(DEV), torch.full((1,), 749.0)).clone()
+    r = rel_l2(got, ref)
+    results_log["unet_full_B1_L64_rel_l2"] = r
+    print(f"[parity] FULL SDXL UNet B=1 512^2: rel_l2={r:.3e} max|ref|={ref.abs().max():.3f} ops={prog.prog_step.num_ops}")
+    assert torch.isfinite(got).all() and r <= 1e-2
+    del net, prog
+    torch.cuda.empty_cache()
+
+    vcfg = R.VAECfg()
+    vw = R.make_weights(R.vae_decoder_spec(vcfg), 1)
+    vnet = n.NativeVAEDecoder(n.VAEConfig(**dataclasses.asdict(vcfg)), n.DictProvider(vw), DEV)
+    z = torch.randn(1, 4, 64, 64, generator=g).half()
+    ref_img = R.vae_decode(vcfg, vw, z.float() / vcfg.scaling_factor)
+    ref_u8 = R.postprocess_u8(ref_img)
+    vprog = vnet.build(1, 64)
+    got_u8 = vprog.decode(z.to(DEV)).cpu().numpy()
+    rv = rel_l2(vprog.image_f32[..., :3].permute(0, 3, 1, 2), ref_img)
+    d = np.abs(got_u8.astype(np.int32) - ref_u8.astype(np.int32))
+    results_log["vae_full_L64"] = {"rel_l2": rv, "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean())}
+    print(f"[parity] FULL SDXL VAE 512^2: rel_l2={rv:.3e} mean|du8|={d.mean():.3f} within4={(d <= 4).mean():.4f}")
+    assert rv <= 1e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99
