@@ -97,7 +97,7 @@ def cpu_baseline(unet_w, vae_w):
     """Bounded CPU sample on this host: one fp32 UNet forward + one fp32 VAE decode of the oracle
     at the benchmark shapes (B=1, 64x64 latent), scaled by the transition census (38 / 17)."""
     from oracle import sdxl_ref as R
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)     # more threads than this only slows torch's CPU GEMMs down
     torch.set_num_threads(cores)
     ucfg, vcfg = R.UNetCfg(sample_size=64), R.VAECfg()
     g = torch.Generator().manual_seed(0)

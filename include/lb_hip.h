@@ -96,6 +96,7 @@ typedef struct LbGemmParams {
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
 void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1/2/3 and split-K */
+void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached
  *      from diffusers_holder.py:336 and :135) ------------------------------------------- */

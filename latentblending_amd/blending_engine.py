@@ -256,19 +256,18 @@ class BlendingEngine:
             self.seed1, self.seed2 = fixed_seeds[0], fixed_seeds[1]
 
         steps = self.num_inference_steps
-        if recycle_img1 and len(self.tree_latents[0]) == steps:
-            first = self.tree_latents[0]
+        use_frontier = self.frontier_width > 1 and _is_native(self.dh.pipe)
+        keep1 = recycle_img1 and len(self.tree_latents[0]) == steps
+        keep2 = recycle_img2 and len(self.tree_latents[-1]) == steps
+        if use_frontier and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0:
+            first, last = self._compute_anchors_batched()
         else:
-            first = self.compute_latents1()
-        if recycle_img2 and len(self.tree_latents[-1]) == steps:
-            last = self.tree_latents[-1]
-        else:
-            last = self.compute_latents2()
+            first = self.tree_latents[0] if keep1 else self.compute_latents1()
+            last = self.tree_latents[-1] if keep2 else self.compute_latents2()
 
         frames = self._decode_many([first[-1], last[-1]])
         self._tree.reset(first, last, frames[0], frames[1])
 
-        use_frontier = self.frontier_width > 1 and _is_native(self.dh.pipe)
         for level in tqdm(range(len(self.list_idx_injection)), disable=not self.verbose):
             stems = int(self.list_nmb_stems[level])
             idx_injection = int(self.list_idx_injection[level])
@@ -309,6 +308,22 @@ class BlendingEngine:
             traj = self.run_diffusion(cond, start)
         self.tree_latents[-1] = traj
         return self.dh.latent2image(traj[-1]) if return_image else traj
+
+    def _compute_anchors_batched(self):
+        """Both anchors as ONE batch-2 denoising run (native pipes; they are independent when the
+        first anchor is not crossfed into the second).  Halves the number of weight-streaming
+        UNet passes of the anchor phase; results equal the two sequential runs."""
+        t0 = time.time()
+        self.dh.set_num_inference_steps(self.num_inference_steps)
+        conds = [self.get_mixed_conditioning(0)[0], self.get_mixed_conditioning(1)[0]]
+        starts = [self.get_noise(self.seed1), self.get_noise(self.seed2)]
+        zeros = [0.0] * self.num_inference_steps
+        first, last = self.dh.pipe.native_run_diffusion_batch(
+            conds, starts, 0, [None, None], [zeros, zeros], num_inference_steps=self.num_inference_steps,
+            guidance_scales=[self.guidance_scale, self.guidance_scale])
+        self.dt_unet_step = (time.time() - t0) / self.num_inference_steps
+        self.tree_latents[0], self.tree_latents[-1] = first, last
+        return first, last
 
     def _parental_mix(self, b_parent1, b_parent2, fract_parental):
         """Slerp the two parents' trajectories step by step (``None`` where either has no latent)."""

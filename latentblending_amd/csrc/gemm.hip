@@ -15,9 +15,14 @@
 // swapped (a = W fragment, b = A fragment) so that each lane owns 4 CONSECUTIVE output columns
 // of one row -> 8-byte stores and vector bias/residual loads.  LDS tiles are [rows][64] halves
 // (128-B rows) with the 16-B chunk index XOR-swizzled by (row & 7) so ds_read_b128 fragment
-// reads spread over the 64 banks.  Global->register->LDS staging is software-pipelined one K-tile
-// ahead (loads issued before the MFMAs of the current tile, LDS written after them, one barrier
-// per K-tile, two LDS buffers).
+// reads spread over the 64 banks.
+//
+// Memory pipeline: a D-deep REGISTER ring of K-tiles.  Tile t+D is requested from HBM/L2 while
+// tile t is multiplied out of LDS and tile t+1 is moved from registers to the other LDS buffer
+// (one barrier per K-tile).  With the small tiles the UNet needs at batch 1-8 a K-tile's MFMAs
+// take ~200-500 cycles but a global load ~1-2k cycles, so one tile in flight (D=1) leaves the
+// loop latency-bound; D = 3-4 keeps enough bytes in flight per CU.  All loads are branch-free:
+// out-of-range chunks read a valid dummy address and are zeroed when they are written to LDS.
 //
 // Replaces (third party, reached from /root/reference/latentblending/diffusers_holder.py:336
 // and :135): every torch.nn.Linear / Conv2d inside diffusers' UNet2DConditionModel and
@@ -27,7 +32,9 @@
 
 #define BK 64
 
-template <int BM, int BN, bool CONV, bool GEGLU>
+template <int N> struct Int { static constexpr int value = N; };
+
+template <int BM, int BN, bool CONV, bool GEGLU, int D>
 __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
     constexpr int AI = BM * 8 / 256;        // 16-B chunks of A per thread per K-tile
     constexpr int WI = BN * 8 / 256;
@@ -80,11 +87,11 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
             const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_off[i] = (long)b * p.Hin * p.Win * p.ldx;
+            a_off[i] = a_ok[i] ? (long)b * p.Hin * p.Win * p.ldx : 0;
             a_iy[i] = oy * p.stride - p.pad;
             a_ix[i] = ox * p.stride - p.pad;
         } else {
-            a_off[i] = (long)m * p.lda;
+            a_off[i] = a_ok[i] ? (long)m * p.lda : 0;
             a_iy[i] = a_ix[i] = 0;
         }
     }
@@ -109,34 +116,42 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
             n = n0 + tr;
             w_ok[i] = n < p.N;
         }
-        w_off[i] = (long)n * p.ldw;
+        w_off[i] = w_ok[i] ? (long)n * p.ldw : 0;
     }
 
-    f16x8 a_reg[AI], w_reg[WI];
+    f16x8 a_reg[D][AI], w_reg[D][WI];
+    unsigned valid[D];                      // bit i: A chunk i real, bit 8+i: W chunk i real
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int hin_eff = p.Hin << p.ups, win_eff = p.Win << p.ups;
 
-    auto load_tile = [&]() {
+    // Branch-free tile request into ring slot S (addresses of masked chunks fall back to offset 0
+    // of the same operand, which is always mapped); advances this thread's k state by one K-tile.
+    auto load_tile = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
         const bool k_ok = kcur < p.K;
+        const int kk = k_ok ? kcur : 0;
+        unsigned v = 0;
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
-            a_reg[i] = zero8;
             if (CONV) {
                 const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-                if (a_ok[i] && k_ok && iy >= 0 && iy < hin_eff && ix >= 0 && ix < win_eff)
-                    a_reg[i] = *reinterpret_cast<const f16x8*>(
-                        p.A + a_off[i] + ((long)(iy >> p.ups) * p.Win + (ix >> p.ups)) * p.ldx + ci);
+                const bool ok = a_ok[i] && k_ok && iy >= 0 && iy < hin_eff && ix >= 0 && ix < win_eff;
+                const long off = ok ? a_off[i] + ((long)(iy >> p.ups) * p.Win + (ix >> p.ups)) * p.ldx + ci : 0;
+                a_reg[S][i] = *reinterpret_cast<const f16x8*>(p.A + off);
+                v |= ok ? (1u << i) : 0u;
             } else {
-                if (a_ok[i] && k_ok)
-                    a_reg[i] = *reinterpret_cast<const f16x8*>(p.A + a_off[i] + kcur);
+                const bool ok = a_ok[i] && k_ok;
+                a_reg[S][i] = *reinterpret_cast<const f16x8*>(p.A + a_off[i] + (a_ok[i] ? kk : 0));
+                v |= ok ? (1u << i) : 0u;
             }
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-            w_reg[i] = zero8;
-            if (w_ok[i] && k_ok) w_reg[i] = *reinterpret_cast<const f16x8*>(p.W + w_off[i] + kcur);
+            const bool ok = w_ok[i] && k_ok;
+            w_reg[S][i] = *reinterpret_cast<const f16x8*>(p.W + w_off[i] + (w_ok[i] ? kk : 0));
+            v |= ok ? (1u << (8 + i)) : 0u;
         }
-        // advance this thread's k state to the next K-tile
+        valid[S] = v;
         kcur += BK;
         if (CONV) {
             ci += BK;
@@ -147,16 +162,20 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](auto sc, int buf) {
+        constexpr int S = decltype(sc)::value;
+        const unsigned v = valid[S];
 #pragma unroll
         for (int i = 0; i < AI; ++i) {
             const int r = row0 + i * 32;
-            *reinterpret_cast<f16x8*>(As + buf * BM * BK + r * BK + ((slot ^ (r & 7)) << 3)) = a_reg[i];
+            *reinterpret_cast<f16x8*>(As + buf * BM * BK + r * BK + ((slot ^ (r & 7)) << 3)) =
+                (v >> i) & 1u ? a_reg[S][i] : zero8;
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int r = row0 + i * 32;
-            *reinterpret_cast<f16x8*>(Ws + buf * BN * BK + r * BK + ((slot ^ (r & 7)) << 3)) = w_reg[i];
+            *reinterpret_cast<f16x8*>(Ws + buf * BN * BK + r * BK + ((slot ^ (r & 7)) << 3)) =
+                (v >> (8 + i)) & 1u ? w_reg[S][i] : zero8;
         }
     };
 
@@ -166,15 +185,7 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (nkt > 0) {
-        load_tile();
-        store_tile(0);
-    }
-    __syncthreads();
-
-    for (int t = 0; t < nkt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nkt) load_tile();       // global loads in flight under the MFMAs below
+    auto compute = [&](int buf) {
         const f16* Ab = As + buf * BM * BK + (wave_m * (BM / 2)) * BK;
         const f16* Wb = Ws + buf * BN * BK + (wave_n * (BN / 2)) * BK;
 #pragma unroll
@@ -197,8 +208,30 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < nkt) store_tile(buf ^ 1);
+    };
+
+    // one K-tile: tile t sits in LDS buf (t&1); ring slot S is free (its tile is the one in LDS)
+    auto stage = [&](auto sc, int t) {
+        constexpr int S = decltype(sc)::value;
+        if (t + D < nkt) load_tile(Int<S>{});                       // request tile t+D
+        compute(t & 1);
+        if (t + 1 < nkt) store_tile(Int<(S + 1) % D>{}, (t + 1) & 1);  // tile t+1: registers -> LDS
         __syncthreads();
+    };
+
+    // ---- prologue: tiles 0..D-1 in flight, tile 0 into LDS ---------------------------------
+    if (nkt > 0) load_tile(Int<0>{});
+    if (D > 1 && nkt > 1) load_tile(Int<1 % D>{});
+    if (D > 2 && nkt > 2) load_tile(Int<2 % D>{});
+    if (D > 3 && nkt > 3) load_tile(Int<3 % D>{});
+    if (nkt > 0) store_tile(Int<0>{}, 0);
+    __syncthreads();
+
+    for (int t0 = 0; t0 < nkt; t0 += D) {
+        stage(Int<0>{}, t0);
+        if (D > 1 && t0 + 1 < nkt) stage(Int<1 % D>{}, t0 + 1);
+        if (D > 2 && t0 + 2 < nkt) stage(Int<2 % D>{}, t0 + 2);
+        if (D > 3 && t0 + 3 < nkt) stage(Int<3 % D>{}, t0 + 3);
     }
 
     // ---- epilogue -------------------------------------------------------------------------
@@ -265,31 +298,43 @@ __global__ void gemm_splitk_reduce_kernel(const LbGemmParams p) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN>
+template <int BM, int BN, int D>
 static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
     if (p.conv) {
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, true, false>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, true, false, D>), grid, dim3(256), 0, stream, p);
     } else if (geglu) {
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, false, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, false, true, D>), grid, dim3(256), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, false, false>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, false, false, D>), grid, dim3(256), 0, stream, p);
     }
 }
 
 static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64
 static int g_force_splitk = 0;    // 0 auto
+static int g_depth = 0;           // 0 = per-tile default ring depth, 1 = single tile in flight (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
+extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 
 extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     // enough for the largest split the heuristic can pick (<= 16 slabs)
     return (long)16 * M * N * (long)sizeof(float);
 }
 
-static int gemm_launch_impl(LbGemmParams p, int tile, dim3 grid, hipStream_t stream) {
-    if (tile == 1) launch_variant<128, 128>(p, grid, stream);
-    else if (tile == 2) launch_variant<128, 64>(p, grid, stream);
-    else launch_variant<64, 64>(p, grid, stream);
+static int gemm_launch_impl(LbGemmParams p, int tile, int depth, dim3 grid, hipStream_t stream) {
+    if (depth == 1) {
+        if (tile == 1) launch_variant<128, 128, 1>(p, grid, stream);
+        else if (tile == 2) launch_variant<128, 64, 1>(p, grid, stream);
+        else launch_variant<64, 64, 1>(p, grid, stream);
+    } else {
+        if (tile == 1) {
+            // 128x128: a second ring slot fits the 256-register budget (2 blocks/CU) only for the
+            // plain variant; the conv / GEGLU variants keep one tile in flight.
+            if (p.conv || (p.flags & LB_GEMM_GEGLU)) launch_variant<128, 128, 1>(p, grid, stream);
+            else launch_variant<128, 128, 2>(p, grid, stream);
+        } else if (tile == 2) launch_variant<128, 64, 3>(p, grid, stream);
+        else launch_variant<64, 64, 4>(p, grid, stream);
+    }
     int rc = lb_check_launch("lb_gemm_f16");
     if (rc) return rc;
     if (p.splitk > 1) {
@@ -347,7 +392,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         if (splitk < 1) splitk = 1;
     }
     p.splitk = splitk;
-
+    const int depth = g_depth;
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
-    LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, grid, s));
+    LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, grid, s));
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lb_gemm_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_gemm_workspace_bytes": (_l, [_i, _i]),
     "lb_gemm_set_tuning": (None, [_i, _i]),
+    "lb_gemm_set_depth": (None, [_i]),
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
     "lb_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "lb_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
@@ -93,7 +94,7 @@ SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

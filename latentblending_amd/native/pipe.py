@@ -262,6 +262,14 @@ class StableDiffusionXLPipeline:
         rows = [sched.step_row(i, float(guidance_scales[g])) for i in range(idx_start, num_inference_steps)
                 for g in range(G)]
         params_all = ops.step_params(rows, self.device).view(-1, G, 8) if rows else None
+        # ancestral noise is drawn sample-major (all steps of branch 0, then branch 1, ...): the same
+        # order a sequential engine consumes a noise tape in, so batching does not change results
+        noise_all = None
+        if sched.ancestral and num_inference_steps > idx_start:
+            shape1 = (1,) + tuple(latents.shape[1:])
+            per_branch = [torch.cat([sched.draw_noise(shape1, self.device)
+                                     for _ in range(idx_start, num_inference_steps)]) for _ in range(G)]
+            noise_all = torch.stack(per_branch, dim=1).contiguous()       # [steps, G, 4, L, L]
         for i in range(idx_start, num_inference_steps):
             if i > 0:
                 mix = [g for g in range(G) if coeffs_list[g][i] > 0]
@@ -283,9 +291,7 @@ class StableDiffusionXLPipeline:
             prog.prog_step.launch(stream)
             self.stats["unet_forwards"] += 1
             self.stats["unet_samples"] += prog.B
-            noise = None
-            if sched.ancestral:
-                noise = torch.cat([sched.draw_noise((1,) + tuple(latents.shape[1:]), self.device) for _ in range(G)])
+            noise = noise_all[i - idx_start] if noise_all is not None else None
             latents = ops.euler_step(latents, prog.eps, params, noise=noise, cfg=cfg, ancestral=sched.ancestral)
             for g in range(G):
                 trajs[g].append(latents[g:g + 1])

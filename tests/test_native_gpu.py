@@ -218,7 +218,7 @@ def test_full_size_sdxl_unet_and_vae(results_log):
     ctx = torch.randn(1, 77, 2048, generator=g).half()
     te = torch.randn(1, 1280, generator=g).half()
     ids = torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]])
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     ref = R.unet_forward(ucfg, w, x, torch.tensor(749.0), ctx, te, ids)
     del w
     prog = net.build(1, 64)
