@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
     int kt_end = kt_begin + tiles_per_split;
     if (kt_end > k_tiles_total) kt_end = k_tiles_total;
     const int nkt = kt_end - kt_begin;
+    const int k_end = kt_end * BK < p.K ? kt_end * BK : p.K;   // loads at k >= k_end are masked to zero
 
     const int slot = tid & 7;               // logical 16-B chunk (8 halves) within the K-tile
     const int row0 = tid >> 3;              // first tile row this thread stages (then +32)
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
     // of the same operand, which is always mapped); advances this thread's k state by one K-tile.
     auto load_tile = [&](auto sc) {
         constexpr int S = decltype(sc)::value;
-        const bool k_ok = kcur < p.K;
+        const bool k_ok = kcur < k_end;
         const int kk = k_ok ? kcur : 0;
         unsigned v = 0;
 #pragma unroll
@@ -155,9 +156,18 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
         kcur += BK;
         if (CONV) {
             ci += BK;
-            while (ci >= p.Cin) {
-                ci -= p.Cin;
-                if (++kx == p.KW) { kx = 0; ++ky; }
+            if (p.Cin >= BK) {              // at most one tap boundary per K-tile: branch-free wrap
+                const bool wrap = ci >= p.Cin;
+                ci -= wrap ? p.Cin : 0;
+                kx += wrap ? 1 : 0;
+                const bool wrapx = kx == p.KW;
+                kx = wrapx ? 0 : kx;
+                ky += wrapx ? 1 : 0;
+            } else {
+                while (ci >= p.Cin) {
+                    ci -= p.Cin;
+                    if (++kx == p.KW) { kx = 0; ++ky; }
+                }
             }
         }
     };
@@ -210,28 +220,38 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
         }
     };
 
-    // one K-tile: tile t sits in LDS buf (t&1); ring slot S is free (its tile is the one in LDS)
+    // One K-tile, NO branches: tile t sits in LDS buf (t&1) and ring slot S is free (its tile is
+    // the one in LDS).  Requests past the end of this block's K range are masked (zero tiles), so
+    // the steady-state loop is straight-line code and the compiler can keep counted vmcnt waits
+    // (a conditional around the loads makes it fall back to vmcnt(0) = one tile in flight).
     auto stage = [&](auto sc, int t) {
         constexpr int S = decltype(sc)::value;
-        if (t + D < nkt) load_tile(Int<S>{});                       // request tile t+D
+        load_tile(Int<S>{});                                        // request tile t+D
         compute(t & 1);
-        if (t + 1 < nkt) store_tile(Int<(S + 1) % D>{}, (t + 1) & 1);  // tile t+1: registers -> LDS
+        store_tile(Int<(S + 1) % D>{}, (t + 1) & 1);                // tile t+1: registers -> LDS
         __syncthreads();
     };
 
     // ---- prologue: tiles 0..D-1 in flight, tile 0 into LDS ---------------------------------
-    if (nkt > 0) load_tile(Int<0>{});
-    if (D > 1 && nkt > 1) load_tile(Int<1 % D>{});
-    if (D > 2 && nkt > 2) load_tile(Int<2 % D>{});
-    if (D > 3 && nkt > 3) load_tile(Int<3 % D>{});
-    if (nkt > 0) store_tile(Int<0>{}, 0);
+    load_tile(Int<0>{});
+    if (D > 1) load_tile(Int<1 % D>{});
+    if (D > 2) load_tile(Int<2 % D>{});
+    if (D > 3) load_tile(Int<3 % D>{});
+    store_tile(Int<0>{}, 0);
     __syncthreads();
 
-    for (int t0 = 0; t0 < nkt; t0 += D) {
-        stage(Int<0>{}, t0);
-        if (D > 1 && t0 + 1 < nkt) stage(Int<1 % D>{}, t0 + 1);
-        if (D > 2 && t0 + 2 < nkt) stage(Int<2 % D>{}, t0 + 2);
-        if (D > 3 && t0 + 3 < nkt) stage(Int<3 % D>{}, t0 + 3);
+    int t = 0;
+    for (; t + D <= nkt; t += D) {                                  // steady state: straight-line body
+        stage(Int<0>{}, t);
+        if (D > 1) stage(Int<1 % D>{}, t + 1);
+        if (D > 2) stage(Int<2 % D>{}, t + 2);
+        if (D > 3) stage(Int<3 % D>{}, t + 3);
+    }
+    {                                                               // remainder (< D tiles), once
+        const int r = nkt - t;
+        if (r > 0) stage(Int<0>{}, t);
+        if (D > 2 && r > 1) stage(Int<1 % D>{}, t + 1);
+        if (D > 3 && r > 2) stage(Int<2 % D>{}, t + 2);
     }
 
     // ---- epilogue -------------------------------------------------------------------------
