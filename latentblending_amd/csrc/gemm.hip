@@ -332,7 +332,7 @@ static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream)
 
 static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64
 static int g_force_splitk = 0;    // 0 auto
-static int g_depth = 0;           // 0 = per-tile default ring depth, 1 = single tile in flight (A/B testing)
+static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
 extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 
@@ -341,20 +341,28 @@ extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     return (long)16 * M * N * (long)sizeof(float);
 }
 
-static int gemm_launch_impl(LbGemmParams p, int tile, int depth, dim3 grid, hipStream_t stream) {
-    if (depth == 1) {
-        if (tile == 1) launch_variant<128, 128, 1>(p, grid, stream);
-        else if (tile == 2) launch_variant<128, 64, 1>(p, grid, stream);
-        else launch_variant<64, 64, 1>(p, grid, stream);
-    } else {
-        if (tile == 1) {
-            // 128x128: a second ring slot fits the 256-register budget (2 blocks/CU) only for the
-            // plain variant; the conv / GEGLU variants keep one tile in flight.
-            if (p.conv || (p.flags & LB_GEMM_GEGLU)) launch_variant<128, 128, 1>(p, grid, stream);
-            else launch_variant<128, 128, 2>(p, grid, stream);
-        } else if (tile == 2) launch_variant<128, 64, 3>(p, grid, stream);
-        else launch_variant<64, 64, 4>(p, grid, stream);
+template <int BM, int BN>
+static void launch_depth(const LbGemmParams& p, int depth, dim3 grid, hipStream_t stream) {
+    switch (depth) {
+        case 1: launch_variant<BM, BN, 1>(p, grid, stream); break;
+        case 2: launch_variant<BM, BN, 2>(p, grid, stream); break;
+        case 3: launch_variant<BM, BN, 3>(p, grid, stream); break;
+        default: launch_variant<BM, BN, 4>(p, grid, stream); break;
     }
+}
+
+// default ring depth per tile (measured on MI355X, tools/sweep_gemm.py); 0 in g_depth = use these
+static int default_depth(const LbGemmParams& p, int tile) {
+    if (tile == 1) return p.conv ? 1 : 3;    // 128x128: conv gather + 3 slots exceeds the register budget
+    if (tile == 2) return 3;
+    return 4;
+}
+
+static int gemm_launch_impl(LbGemmParams p, int tile, int depth, dim3 grid, hipStream_t stream) {
+    if (depth <= 0) depth = default_depth(p, tile);
+    if (tile == 1) launch_depth<128, 128>(p, depth, grid, stream);
+    else if (tile == 2) launch_depth<128, 64>(p, depth, grid, stream);
+    else launch_depth<64, 64>(p, depth, grid, stream);
     int rc = lb_check_launch("lb_gemm_f16");
     if (rc) return rc;
     if (p.splitk > 1) {
@@ -391,11 +399,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         return (long)((p.M + bm - 1) / bm) * ((n_eff + bn_eff - 1) / bn_eff);
     };
     int tile = g_force_tile;
-    if (!tile) {
-        if (blocks(128, 128) >= 224) tile = 1;
-        else if (blocks(128, 64) >= 224) tile = 2;
-        else tile = 3;
-    }
+    if (!tile) tile = blocks(128, 128) >= 224 ? 1 : 3;   // 128x64 never won the sweep (tools/sweep_gemm.py)
     const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
     const long nblk = blocks(bm, bn);
     int splitk = 1;
@@ -403,8 +407,10 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         const int k_tiles = (p.K + BK - 1) / BK;
         if (g_force_splitk) splitk = g_force_splitk;
         else if (nblk < 160) {
-            splitk = (int)((256 + nblk - 1) / nblk);
-            const int max_by_k = k_tiles / 4 > 0 ? k_tiles / 4 : 1;   // >= 4 K-tiles per slice
+            // long-K, few-tile problems (M = 256..512 rows against K up to 23040): aim at ~2.5 blocks
+            // per CU but keep >= 16 K-tiles per slice so the slab round trip stays negligible
+            splitk = (int)((640 + nblk - 1) / nblk);
+            const int max_by_k = k_tiles / 16 > 0 ? k_tiles / 16 : 1;
             if (splitk > max_by_k) splitk = max_by_k;
             if (splitk > 16) splitk = 16;
         }
