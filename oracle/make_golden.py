@@ -1,0 +1,223 @@
+"""ORACLE — test infrastructure.  Generates tests/golden/*.json by EXECUTING the unchanged reference
+(/root/reference, imported through oracle/ref_harness.py) in this container.  The GPU box has no
+/root/reference, so everything the tests need from it is frozen here.
+
+    python -m oracle.make_golden
+
+Fixtures
+  planner.json    get_time_based_branching / set_branching / crossfeed coefficient vectors /
+                  guidance mid-dampening / get_closest_idx produced by the reference's own methods
+  slerp.json      interpolate_spherical / interpolate_linear of the reference on seeded small inputs
+                  (fp16 results stored as int16 bit patterns -> bit-exact comparisons)
+  scheduler.json  closed-form SDXL sigma / timestep known answers
+  tree.json       a full run_transition of the reference BlendingEngine on the tiny CPU oracle pipe:
+                  census, tree_fracts, tree_idx_injection, similarities, latent / frame checksums
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import pipe as OP
+from . import ref_harness as H
+from . import sdxl_ref as R
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def bits16(t: torch.Tensor):
+    return t.detach().contiguous().view(torch.int16).flatten().tolist()
+
+
+def sha(t) -> str:
+    a = np.ascontiguousarray(np.asarray(t) if not isinstance(t, torch.Tensor) else t.detach().cpu().numpy())
+    return hashlib.sha256(a.tobytes()).hexdigest()[:16]
+
+
+def seeded(n, seed, dtype=torch.float16, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(n, generator=g) * scale).to(dtype)
+
+
+def tiny_pipe(turbo=True):
+    return OP.StableDiffusionXLPipeline(turbo=turbo, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+
+
+def planner_fixture(ref):
+    out = {"time_based": [], "turbo": [], "parental_coeffs": [], "anchor_coeffs": [], "guidance": [], "closest_idx": []}
+    with H.cuda_is_identity():
+        be = ref.BlendingEngine(tiny_pipe(turbo=False))
+        for steps, depth, nmb in [(30, 0.5, 15), (30, 0.5, 64), (30, 0.5, 5), (30, 0.5, 3), (30, 0.2, 15), (50, 0.5, 15),
+                                  (10, 0.2, 7), (6, 0.5, 6), (20, 0.35, 9)]:
+            be.num_inference_steps = steps
+            idx, stems = be.get_time_based_branching(depth, None, nmb)
+            out["time_based"].append({"steps": steps, "depth": depth, "nmb": nmb, "idx": [int(i) for i in idx],
+                                      "stems": [int(s) for s in stems]})
+        for steps, depth, tmax, dtu, dtv in [(30, 0.5, 20, 0.05, 0.1), (30, 0.3, 5, 0.02, 0.2), (50, 0.5, 60, 0.1, 0.5)]:
+            be.num_inference_steps, be.dt_unet_step, be.dt_vae = steps, dtu, dtv
+            idx, stems = be.get_time_based_branching(depth, tmax, None)
+            out["time_based"].append({"steps": steps, "depth": depth, "tmax": tmax, "dt_unet": dtu, "dt_vae": dtv,
+                                      "idx": [int(i) for i in idx], "stems": [int(s) for s in stems]})
+        # guidance dampening (blending_engine.py:155-164)
+        for base, damper in [(4.0, 0.5), (7.5, 0.3), (0.0, 0.5)]:
+            be.guidance_scale_base, be.guidance_scale_mid_damper = base, damper
+            row = []
+            for f in [0.0, 0.125, 0.25, 0.5, 0.75, 1.0]:
+                be.set_guidance_mid_dampening(f)
+                row.append(float(be.guidance_scale))
+            out["guidance"].append({"base": base, "damper": damper, "fracts": [0.0, 0.125, 0.25, 0.5, 0.75, 1.0], "values": row})
+        # get_closest_idx (docstring example + more)
+        for fracts, q in [([0, 0.3, 0.6, 1.0], 0.4), ([0.0, 1.0], 0.5), ([0.0, 0.25, 0.5, 1.0], 0.125), ([0.0, 0.5, 1.0], 0.75)]:
+            be.tree_fracts = list(fracts)
+            a, b = be.get_closest_idx(q)
+            out["closest_idx"].append({"fracts": fracts, "q": q, "result": [int(a), int(b)]})
+
+        # crossfeed coefficient vectors as the reference builds them inside compute_latents_mix / compute_latents2:
+        # capture the mixing_coeffs argument that reaches run_diffusion.
+        def capture(engine, call):
+            seen = {}
+            original = engine.run_diffusion
+
+            def spy(list_conditionings, latents_start=None, idx_start=0, list_latents_mixing=None, mixing_coeffs=0.0,
+                    return_image=False):
+                seen["coeffs"] = [float(c) for c in mixing_coeffs] if isinstance(mixing_coeffs, list) else mixing_coeffs
+                raise StopIteration
+            engine.run_diffusion = spy
+            try:
+                call()
+            except StopIteration:
+                pass
+            engine.run_diffusion = original
+            return seen["coeffs"]
+
+        for turbo, steps, idx_inj, pw, rg, dc in [(True, 4, 2, 1.0, 1.0, 1.0), (True, 4, 1, 0.8, 0.5, 0.5), (True, 8, 3, 0.6, 0.75, 0.3),
+                                                  (False, 30, 15, None, None, None), (False, 30, 24, None, None, None)]:
+            e = ref.BlendingEngine(tiny_pipe(turbo=turbo))
+            e.set_num_inference_steps(steps)
+            if turbo:
+                e.set_parental_crossfeed(pw, rg, dc)
+            e.set_prompt1("a"); e.set_prompt2("b")
+            z = e.get_noise(1)
+            e.tree_latents = [[z] * steps, [z] * steps]
+            e.tree_fracts = [0.0, 1.0]
+            coeffs = capture(e, lambda: e.compute_latents_mix(0.5, 0, 1, idx_inj))
+            out["parental_coeffs"].append({"turbo": turbo, "steps": steps, "idx_injection": idx_inj,
+                                           "power": float(e.parental_crossfeed_power), "range": float(e.parental_crossfeed_range),
+                                           "decay": float(e.parental_crossfeed_decay), "coeffs": coeffs})
+        for steps, pw, rg, dc in [(4, 0.5, 0.5, 0.5), (30, 0.3, 0.6, 0.9), (10, 1.0, 1.0, 0.1)]:
+            e = ref.BlendingEngine(tiny_pipe(turbo=True))
+            e.set_num_inference_steps(steps)
+            e.set_branch1_crossfeed(pw, rg, dc)
+            e.set_prompt1("a"); e.set_prompt2("b")
+            z = e.get_noise(1)
+            e.tree_latents = [[z] * steps, None]
+            coeffs = capture(e, e.compute_latents2)
+            out["anchor_coeffs"].append({"steps": steps, "power": pw, "range": rg, "decay": dc, "coeffs": coeffs})
+        # turbo set_branching (blending_engine.py:273-283)
+        e = ref.BlendingEngine(tiny_pipe(turbo=True))
+        for steps, depth, nmb in [(4, None, None), (4, None, 15), (4, 0.5, 3), (2, 0.5, 3), (8, 0.3, 64), (5, 0.5, 7)]:
+            e.set_num_inference_steps(steps)
+            e.set_branching(depth_strength=depth, nmb_max_branches=nmb)
+            out["turbo"].append({"steps": steps, "depth": depth, "nmb": nmb, "idx": [int(i) for i in e.list_idx_injection],
+                                 "stems": [int(s) for s in e.list_nmb_stems]})
+    return out
+
+
+def slerp_fixture(ref):
+    cases = []
+    U = ref.utils
+
+    def add(name, p0, p1, f):
+        r = U.interpolate_spherical(p0, p1, f)
+        entry = {"name": name, "fract": f, "in_dtype": str(p0.dtype), "out_dtype": str(r.dtype), "n": p0.numel(),
+                 "seed0": None, "nan": bool(torch.isnan(r).all())}
+        if r.dtype == torch.float16:
+            entry["out_bits"] = bits16(r)
+        else:
+            entry["out_f32"] = [float(x) for x in r.flatten().tolist()]
+        return entry
+
+    for n in (64, 257):
+        p0, p1 = seeded(n, 100 + n, scale=3.0), seeded(n, 200 + n, scale=3.0)
+        for f in (0.0, 0.25, 0.37, 0.5, 1.0):
+            e = add(f"f16_n{n}", p0, p1, f)
+            e.update(seed0=100 + n, seed1=200 + n, scale=3.0)
+            cases.append(e)
+    a = seeded(64, 7)
+    for name, x, y, f in [("identical", a, a.clone(), 0.3), ("antipodal", a, -a, 0.5), ("zero_norm", torch.zeros(64, dtype=torch.float16), a, 0.5)]:
+        e = add(name, x, y, f)
+        e.update(seed0=7, seed1=None, scale=1.0)
+        cases.append(e)
+    for dt in (torch.float32, torch.float64):
+        x, y = seeded(33, 11, dt), seeded(33, 12, dt)
+        e = add(f"dtype_{str(dt).split('.')[-1]}", x, y, 0.41)
+        e.update(seed0=11, seed1=12, scale=1.0)
+        cases.append(e)
+    lerps = []
+    for f in (0.0, 0.125, 0.5, 0.7321, 1.0):
+        x, y = seeded(96, 21), seeded(96, 22)
+        lerps.append({"fract": f, "seed0": 21, "seed1": 22, "n": 96, "out_bits": bits16(U.interpolate_linear(x, y, f))})
+    u8a = (np.arange(48, dtype=np.uint8).reshape(4, 4, 3) * 5) % 255
+    u8b = (np.arange(48, dtype=np.uint8)[::-1].reshape(4, 4, 3) * 3) % 255
+    lerps.append({"fract": 0.3, "uint8": True, "a": u8a.flatten().tolist(), "b": u8b.flatten().tolist(),
+                  "out": U.interpolate_linear(u8a, u8b, 0.3).flatten().tolist()})
+    return {"slerp": cases, "lerp": lerps}
+
+
+def scheduler_fixture():
+    return {
+        "sigma_999": 14.614641, "trailing4_timesteps": [999, 749, 499, 249],
+        "trailing4_sigmas": [14.61464, 4.08173, 1.61289, 0.69320, 0.0],
+        "trailing4_ancestral": [[3.91930, 1.13999], [1.48163, 0.63733], [0.62591, 0.29793], [0.0, 0.0]],
+        "leading30_first": 958, "leading30_last": 1, "leading30_sigma0": 11.47685, "leading30_init_noise_sigma": 11.52033,
+        "source": "closed form from SDXL scaled_linear betas [0.00085, 0.012], 1000 steps (SURVEY.md §4)",
+    }
+
+
+def tree_fixture(ref):
+    runs = []
+    for turbo, cfgd in [(True, dict(nmb=5)), (True, dict(nmb=3, steps=2, depth=0.5)), (False, dict(nmb=6, steps=6, depth=0.5, gs=3.0))]:
+        p = tiny_pipe(turbo=turbo)
+        np.random.seed(0)
+        with H.cuda_is_identity():
+            be = ref.BlendingEngine(p)
+            be.set_dimensions((128, 128))
+            if "steps" in cfgd:
+                be.set_num_inference_steps(cfgd["steps"])
+            if "gs" in cfgd:
+                be.set_guidance_scale(cfgd["gs"])
+            be.set_branching(depth_strength=cfgd.get("depth"), nmb_max_branches=cfgd["nmb"])
+            be.set_prompt1("photo of a reef")
+            be.set_prompt2("rendering of an alien planet")
+            p.noise.reset()
+            p.unet.calls = p.vae.calls = 0
+            imgs = be.run_transition(fixed_seeds=[420, 421])
+        runs.append({
+            "turbo": turbo, "config": cfgd, "frames": len(imgs), "unet_calls": p.unet.calls, "vae_calls": p.vae.calls,
+            "noise_draws": p.noise.draws, "list_idx_injection": [int(i) for i in be.list_idx_injection],
+            "list_nmb_stems": [int(s) for s in be.list_nmb_stems],
+            "tree_fracts": [float(f) for f in be.tree_fracts], "tree_idx_injection": [int(i) for i in be.tree_idx_injection],
+            "tree_similarities": [float(s) for s in be.tree_similarities],
+            "final_latent_sha": [sha(l[-1]) for l in be.tree_latents], "frame_sha": [sha(i) for i in imgs],
+            "none_pattern": [[x is None for x in l] for l in be.tree_latents],
+        })
+    return runs
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = H.load_reference()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    for name, data in [("planner", planner_fixture(ref)), ("slerp", slerp_fixture(ref)), ("scheduler", scheduler_fixture()),
+                       ("tree", tree_fixture(ref))]:
+        with open(os.path.join(OUT, name + ".json"), "w") as fh:
+            json.dump(data, fh, indent=1)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

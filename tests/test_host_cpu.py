@@ -1,0 +1,367 @@
+"""CPU-only tests (`-m "not gpu"`): the oracle against the golden vectors frozen from the unchanged
+reference, the host logic (planner / tree / engine / holder) against the same vectors, the C-ABI
+export surface, and fail-loud behaviour.  No kernel is launched here.
+"""
+import ctypes
+import dataclasses
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipe as OP
+from oracle import ref_harness as H
+from oracle import sdxl_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name + ".json")) as fh:
+        return json.load(fh)
+
+
+def seeded(n, seed, dtype=torch.float16, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(n, generator=g) * scale).to(dtype)
+
+
+DT = {"torch.float16": torch.float16, "torch.float32": torch.float32, "torch.float64": torch.float64}
+
+
+@pytest.fixture()
+def cpu_backend():
+    from latentblending_amd.backend import set_backend
+    set_backend(R.TorchCpuBackend())
+    yield
+    set_backend(None)
+
+
+def tiny_pipe(turbo=True):
+    return OP.StableDiffusionXLPipeline(turbo=turbo, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+
+
+# ---------------------------------------------------------------- oracle pinned by the reference
+def test_oracle_slerp_matches_reference_golden():
+    for c in gold("slerp")["slerp"]:
+        dt = DT[c["in_dtype"]]
+        if c["name"] == "identical":
+            p0 = seeded(c["n"], c["seed0"]); p1 = p0.clone()
+        elif c["name"] == "antipodal":
+            p0 = seeded(c["n"], c["seed0"]); p1 = -p0
+        elif c["name"] == "zero_norm":
+            p0 = torch.zeros(c["n"], dtype=torch.float16); p1 = seeded(c["n"], c["seed0"])
+        else:
+            p0, p1 = seeded(c["n"], c["seed0"], dt, c["scale"]), seeded(c["n"], c["seed1"], dt, c["scale"])
+        out = R.slerp(p0, p1, c["fract"])
+        assert str(out.dtype) == c["out_dtype"], c["name"]
+        if c["nan"]:
+            assert torch.isnan(out).all()
+        elif out.dtype == torch.float16:
+            assert out.view(torch.int16).tolist() == c["out_bits"], (c["name"], c["fract"])
+        else:
+            assert out.tolist() == c["out_f32"], c["name"]
+
+
+def test_oracle_lerp_matches_reference_golden():
+    from latentblending_amd.utils import interpolate_linear
+    for c in gold("slerp")["lerp"]:
+        if c.get("uint8"):
+            a = np.array(c["a"], dtype=np.uint8).reshape(4, 4, 3)
+            b = np.array(c["b"], dtype=np.uint8).reshape(4, 4, 3)
+            assert interpolate_linear(a, b, c["fract"]).flatten().tolist() == c["out"]   # host path of utils
+            continue
+        x, y = seeded(c["n"], c["seed0"]), seeded(c["n"], c["seed1"])
+        assert R.lerp(x, y, c["fract"]).view(torch.int16).tolist() == c["out_bits"]
+
+
+def test_scheduler_tables_match_closed_form():
+    g = gold("scheduler")
+    for make in (lambda a: R.EulerScheduler(ancestral=a),):
+        s = make(True); s.set_timesteps(4)
+        assert s.timesteps.tolist() == g["trailing4_timesteps"]
+        assert np.allclose(s.sigmas.numpy(), g["trailing4_sigmas"], atol=2e-5)
+        assert abs(s.init_noise_sigma - g["sigma_999"]) < 1e-4
+        for i, (up, down) in enumerate(g["trailing4_ancestral"]):
+            u, d = R.ancestral_sigmas(float(s.sigmas[i]), float(s.sigmas[i + 1]))
+            assert abs(u - up) < 2e-5 and abs(d - down) < 2e-5
+        s = make(False); s.set_timesteps(30)
+        assert int(s.timesteps[0]) == g["leading30_first"] and int(s.timesteps[-1]) == g["leading30_last"]
+        assert abs(float(s.sigmas[0]) - g["leading30_sigma0"]) < 2e-4
+        assert abs(s.init_noise_sigma - g["leading30_init_noise_sigma"]) < 2e-4
+
+
+def test_native_scheduler_tables_equal_oracle():
+    from latentblending_amd.native.scheduler import NativeEulerScheduler
+    for anc, n in [(True, 4), (True, 2), (False, 30), (False, 6), (False, 50)]:
+        a, b = NativeEulerScheduler(anc, device="cpu"), R.EulerScheduler(anc)
+        a.set_timesteps(n); b.set_timesteps(n)
+        assert a.timesteps.tolist() == b.timesteps.tolist()
+        assert a.sigmas.tolist() == b.sigmas.tolist()
+        assert a.init_noise_sigma == b.init_noise_sigma
+        for i in range(n):
+            row = a.step_row(i, 2.5)
+            s_from, s_to = float(b.sigmas[i]), float(b.sigmas[i + 1])
+            if anc:
+                up, down = R.ancestral_sigmas(s_from, s_to)
+                assert row == (s_from, down, up, 2.5, down - s_from)
+            else:
+                assert row == (s_from, s_to, 0.0, 2.5, s_to - s_from)
+
+
+def test_unet_and_vae_parameter_counts():
+    assert R.count_params(R.unet_spec(R.UNetCfg())) == 2_567_463_684
+    assert R.count_params(R.vae_decoder_spec(R.VAECfg())) == 49_490_199
+
+
+# ---------------------------------------------------------------- host logic vs the reference's vectors
+def test_planner_matches_reference_golden():
+    from latentblending_amd import planner
+    g = gold("planner")
+    for c in g["time_based"]:
+        idx, stems = planner.time_based_branching(c["steps"], c["depth"], c.get("dt_unet", 0.0), c.get("dt_vae", 0.0),
+                                                  c.get("tmax"), c.get("nmb"))
+        assert [int(i) for i in idx] == c["idx"] and [int(s) for s in stems] == c["stems"], c
+    for c in g["turbo"]:
+        idx, stems = planner.turbo_branching(c["steps"], c["depth"], c["nmb"])
+        assert idx == c["idx"] and stems == c["stems"], c
+    for c in g["parental_coeffs"]:
+        got = planner.parental_crossfeed_coeffs(c["steps"], c["idx_injection"], c["power"], c["range"], c["decay"])
+        assert [float(x) for x in got] == c["coeffs"], c
+    for c in g["anchor_coeffs"]:
+        got = planner.anchor_crossfeed_coeffs(c["steps"], c["power"], c["range"], c["decay"])
+        assert [float(x) for x in got] == c["coeffs"], c
+    for c in g["guidance"]:
+        got = [float(planner.damped_guidance(c["base"], c["damper"], f)) for f in c["fracts"]]
+        assert got == c["values"], c
+
+
+def test_tree_policy_units():
+    from latentblending_amd.tree import TransitionTree, UNSCORED
+    t = TransitionTree()
+    t.reset(["a"], ["b"], "fa", "fb")
+    assert t.similarities == [UNSCORED] and t.widest_gap() == 0          # reference quirk: first split w/o metric
+    assert t.next_split(2) == (0.5, 0, 1)
+    t.commit(0.5, 2, ["m"], "fm", 0.3, 0.7)
+    assert t.fracts == [0.0, 0.5, 1.0] and t.similarities == [0.3, 0.7] and t.idx_injection == [0, 2, 0]
+    assert t.next_split(2) == (0.75, 0, 2)                                 # parents skip the same-level branch
+    t.commit(0.75, 2, ["n"], "fn", 0.7, 0.7)                               # tie -> first maximum
+    assert t.widest_gap() == 1
+    for c in gold("planner")["closest_idx"]:
+        t.fracts = list(c["fracts"])
+        assert list(t.neighbours(c["q"])) == c["result"]
+
+
+@pytest.mark.parametrize("run", range(3))
+def test_engine_reproduces_reference_transition(run, cpu_backend):
+    """Our host layer, driving the same tiny CPU pipe, reproduces the reference run frozen in
+    tests/golden/tree.json: census, tree, similarities (exact floats), latents and frames (hashes)."""
+    from latentblending_amd import BlendingEngine
+    import hashlib
+    c = gold("tree")[run]
+    cfgd = c["config"]
+    p = tiny_pipe(turbo=c["turbo"])
+    np.random.seed(0)
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+    be.set_dimensions((128, 128))
+    if "steps" in cfgd:
+        be.set_num_inference_steps(cfgd["steps"])
+    if "gs" in cfgd:
+        be.set_guidance_scale(cfgd["gs"])
+    be.set_branching(depth_strength=cfgd.get("depth"), nmb_max_branches=cfgd["nmb"])
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+    p.noise.reset()
+    p.unet.calls = p.vae.calls = 0
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)).tobytes()).hexdigest()[:16]
+    assert len(imgs) == c["frames"] and p.unet.calls == c["unet_calls"] and p.vae.calls == c["vae_calls"]
+    assert p.noise.draws == c["noise_draws"]
+    assert [int(i) for i in be.list_idx_injection] == c["list_idx_injection"]
+    assert [int(s) for s in be.list_nmb_stems] == c["list_nmb_stems"]
+    assert [float(f) for f in be.tree_fracts] == c["tree_fracts"]
+    assert [int(i) for i in be.tree_idx_injection] == c["tree_idx_injection"]
+    assert [float(s) for s in be.tree_similarities] == c["tree_similarities"]
+    assert [[x is None for x in l] for l in be.tree_latents] == c["none_pattern"]
+    assert [sha(l[-1]) for l in be.tree_latents] == c["final_latent_sha"]
+    assert [sha(i) for i in imgs] == c["frame_sha"]
+
+
+@pytest.mark.skipif(not H.reference_available(), reason="/root/reference not mounted")
+def test_live_differential_against_unchanged_reference(cpu_backend):
+    """When the reference is mounted: run it and our engine side by side, including swap_forward +
+    recycle (multi-transition chain, example_multi_trans.py:39-58)."""
+    from latentblending_amd import BlendingEngine
+    ref = H.load_reference()
+    outs = []
+    for which in ("ref", "ours"):
+        p = tiny_pipe(True)
+        np.random.seed(0)
+        with H.cuda_is_identity():
+            be = ref.BlendingEngine(p) if which == "ref" else BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+            be.set_dimensions((128, 128))
+            be.set_branching(nmb_max_branches=3)
+            be.set_branch1_crossfeed(0.3, 0.5, 0.5)
+            frames = []
+            prompts = ["a", "b", "c"]
+            for i in range(2):
+                if i == 0:
+                    be.set_prompt1(prompts[0]); be.set_prompt2(prompts[1])
+                else:
+                    be.swap_forward(); be.set_prompt2(prompts[i + 1])
+                p.noise.reset()
+                frames.append([np.asarray(f) for f in be.run_transition(recycle_img1=i > 0, fixed_seeds=[5 + i, 6 + i])])
+            outs.append((frames, [float(f) for f in be.tree_fracts], p.unet.calls))
+    (fa, ta, ca), (fb, tb, cb) = outs
+    assert ta == tb and ca == cb
+    for x, y in zip(fa, fb):
+        assert len(x) == len(y) and all(np.array_equal(a, b) for a, b in zip(x, y))
+
+
+def test_reference_error_behaviour_is_kept(cpu_backend):
+    from latentblending_amd import BlendingEngine
+    p = tiny_pipe(True)
+    with pytest.raises(AssertionError):
+        BlendingEngine(p, guidance_scale_mid_damper=0.0, metric=R.OracleLPIPS(7), verbose=False)
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+    with pytest.raises(AssertionError):
+        be.set_branching(t_compute_max_allowed=3)                 # turbo: time budget unsupported
+    with pytest.raises(AssertionError):
+        be.run_transition(fixed_seeds=[1, 2, 3])
+    with pytest.raises(AssertionError):
+        be.dh.prepare_mixing([0.1, 0.2], None)                     # wrong coefficient count
+    with pytest.raises(ValueError):
+        be.dh.prepare_mixing((0.1,), None)
+    with pytest.raises(AssertionError):
+        be.run_diffusion(("not", "a", "list"))
+    # cfg-1 as written (num_inference_steps=1) cannot build a tree in the reference either
+    be.set_num_inference_steps(1)
+    be.set_branching(nmb_max_branches=3)
+    be.set_prompt1("a"); be.set_prompt2("b")
+    with pytest.raises((IndexError, TypeError)):
+        be.run_transition(fixed_seeds=[1, 2])
+    base = BlendingEngine(tiny_pipe(False), metric=R.OracleLPIPS(7), verbose=False)
+    with pytest.raises(ValueError):
+        base.set_branching(t_compute_max_allowed=5, nmb_max_branches=5)
+    assert (base.parental_crossfeed_power, base.parental_crossfeed_range, base.parental_crossfeed_decay) == (0.3, 0.6, 0.9)
+
+
+# ---------------------------------------------------------------- boundary
+def test_c_abi_exports_every_declared_symbol():
+    from latentblending_amd.hip import lib
+    header = open(os.path.join(ROOT, "include", "lb_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(lb_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 40
+    cdll = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in declared if not hasattr(cdll, n)]
+    assert not missing, f"declared in include/lb_hip.h but not exported: {missing}"
+    unbound = [n for n in declared if n not in lib.SIGNATURES]
+    assert not unbound, f"declared but not bound in hip/lib.py: {unbound}"
+    assert lib.api.lb_version() >= 10000
+    # struct layout guard: ctypes mirror == what a C compiler makes of the header
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc"):
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "t.c")
+            with open(src, "w") as fh:
+                fh.write('#include <stdio.h>\n#include <stddef.h>\n#include "lb_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+                         'sizeof(LbGemmParams), offsetof(LbGemmParams, splitk), sizeof(LbAttnParams), offsetof(LbAttnParams, scale));return 0;}\n')
+            exe = os.path.join(td, "t")
+            subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+            sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+        assert sizes == [ctypes.sizeof(lib.LbGemmParams), lib.LbGemmParams.splitk.offset,
+                         ctypes.sizeof(lib.LbAttnParams), lib.LbAttnParams.scale.offset]
+
+
+def test_product_path_has_no_cpu_fallback():
+    from latentblending_amd.backend import HipBackend
+    be = HipBackend()
+    a = torch.zeros(8, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        be.slerp(a, a, 0.5)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        be.lerp(a, a, 0.5)
+    if not torch.cuda.is_available():
+        import latentblending_amd.native as N
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            N.NativeSDXLPipe(turbo=True, unet_cfg=N.UNetConfig(**dataclasses.asdict(R.tiny_unet_cfg())))
+    # product modules never import the oracle
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "latentblending_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_launchers_validate_arguments_without_a_gpu():
+    """Argument errors are reported through the C-ABI error channel before anything is launched."""
+    from latentblending_amd.hip import lib
+    p = lib.LbGemmParams()
+    p.M, p.N, p.K, p.lda, p.ldw, p.ldc = 16, 6, 64, 64, 64, 8      # N not a multiple of 4
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        lib.api.lb_gemm_f16(ctypes.byref(p), None)
+    with pytest.raises(RuntimeError, match="n must be a multiple of 8"):
+        lib.api.lb_slerp_batched_f16(16, 16, 16, 16, 2, 12, None)
+
+
+def test_synthetic_provider_equals_oracle_weights():
+    import latentblending_amd.native as N
+
+    class Rec(N.SyntheticProvider):
+        def __init__(self, seed):
+            super().__init__(seed); self.got = {}
+
+        def weight(self, n, *a, **k):
+            self.got[n] = super().weight(n, *a, **k); return self.got[n]
+
+        def bias(self, n, *a):
+            self.got[n] = super().bias(n, *a); return self.got[n]
+
+        def norm_weight(self, n, *a):
+            self.got[n] = super().norm_weight(n, *a); return self.got[n]
+
+        def positive(self, n, *a):
+            self.got[n] = super().positive(n, *a); return self.got[n]
+
+    def same(got, ref):
+        assert set(got) == set(ref)
+        assert all(torch.equal(got[k].reshape(ref[k].shape), ref[k]) for k in ref)
+    oc, vc = R.tiny_unet_cfg(), R.tiny_vae_cfg()
+    rec = Rec(0); N.NativeUNet(N.UNetConfig(**dataclasses.asdict(oc)), rec, "cpu"); same(rec.got, R.make_weights(R.unet_spec(oc), 0))
+    rec = Rec(1); N.NativeVAEDecoder(N.VAEConfig(**dataclasses.asdict(vc)), rec, "cpu"); same(rec.got, R.make_weights(R.vae_decoder_spec(vc), 1))
+    from latentblending_amd.native.lpips import NativeLPIPS
+    rec = Rec(7); NativeLPIPS(rec, "cpu"); same(rec.got, R.make_weights(R.lpips_spec(), 7))
+
+
+def test_host_utilities_and_movie_writer(tmp_path):
+    from latentblending_amd import utils
+    from latentblending_amd.movie import MovieSaver, fill_up_frames_linear_interpolation
+    from latentblending_amd.native.frames import DeviceImage
+    imgs = [np.full((8, 8, 3), v, dtype=np.uint8) for v in (0, 100, 200)]
+    np.random.seed(1)
+    out = utils.add_frames_linear_interp(imgs, nmb_frames_target=10)
+    assert len(out) == 10 and out[0].mean() == 0 and out[-1].mean() == 200
+    assert utils.add_frames_linear_interp(imgs, nmb_frames_target=2) is imgs
+    with pytest.raises(ValueError):
+        utils.add_frames_linear_interp(imgs, fps_target=3, nmb_frames_target=4)
+    assert len(utils.get_spacing(7, 1.0)) == 7 and len(utils.get_spacing(8, 2.0)) == 8 and len(utils.get_spacing(9, 2.0)) == 9
+    assert utils.compare_dicts({"a": 1, "b": 2}, {"a": 1, "b": 3, "c": 4}) == {"b": [2, 3]}
+    assert re.fullmatch(r"\d{6}_\d{6}_\d{3}", utils.get_time("millisecond"))
+    fp = tmp_path / "s.yml"
+    utils.yml_save(str(fp), {"x": 1, "y": [1, 2]})
+    assert utils.yml_load(str(fp)) == {"x": 1, "y": [1, 2]}
+    frames = fill_up_frames_linear_interpolation([DeviceImage(torch.from_numpy(i)) for i in imgs], 2, 5)
+    assert len(frames) == 10
+    saver = MovieSaver(str(tmp_path / "m.avi"), fps=5, shape_hw=[8, 8])
+    for f in frames:
+        saver.write_frame(f)
+    saver.finalize()
+    blob = open(tmp_path / "m.avi", "rb").read()
+    assert blob[:4] == b"RIFF" and blob[8:12] == b"AVI " and blob.count(b"00dc") >= 10
