@@ -45,7 +45,7 @@ except Exception:  # pragma: no cover
 class BlendingEngine:
     def __init__(self, pipe: None, do_compile: bool = False,
                  guidance_scale_mid_damper: float = 0.5, mid_compression_scaler: float = 1.2,
-                 metric=None, frontier_width: int = 1, verbose: bool = True):
+                 metric=None, frontier_width: int = 1, verbose: bool = True, farm=None):
         """
         Args:
             pipe: SDXL pipeline (``NativeSDXLPipe`` for the gfx950 path, or any diffusers-like pipe).
@@ -55,7 +55,11 @@ class BlendingEngine:
             mid_compression_scaler: kept for signature compatibility (unused upstream as well).
             metric: optional perceptual-distance callable ``metric(a, b)`` on ``[1,3,H,W]`` tensors
                 in [-1, 1]; default: the pipe's native LPIPS, else the ``lpips`` package.
-            frontier_width: number of gaps evaluated concurrently (native pipes only).
+            frontier_width: number of gap children evaluated per speculative round (batched on a
+                native pipe); 1 = the reference's strictly sequential loop.
+            farm: ``latentblending_amd.dist.BranchFarm`` — SPMD over ``torch.distributed``: every rank
+                runs this same engine, each round's branches are split over the ranks and
+                all-gathered (RCCL over xGMI on GPUs); decisions are taken identically everywhere.
         """
         assert guidance_scale_mid_damper > 0 and guidance_scale_mid_damper <= 1.0, \
             f"guidance_scale_mid_damper neees to be in interval (0,1], you provided {guidance_scale_mid_damper}"
@@ -68,6 +72,7 @@ class BlendingEngine:
         self.guidance_scale_mid_damper = guidance_scale_mid_damper
         self.mid_compression_scaler = mid_compression_scaler
         self.frontier_width = int(frontier_width)
+        self.farm = farm
         self.seed1 = 0
         self.seed2 = 0
         self.prompt1 = ""
@@ -256,10 +261,13 @@ class BlendingEngine:
             self.seed1, self.seed2 = fixed_seeds[0], fixed_seeds[1]
 
         steps = self.num_inference_steps
-        use_frontier = self.frontier_width > 1 and _is_native(self.dh.pipe)
+        use_frontier = self.frontier_width > 1 or self.farm is not None
         keep1 = recycle_img1 and len(self.tree_latents[0]) == steps
         keep2 = recycle_img2 and len(self.tree_latents[-1]) == steps
-        if use_frontier and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0:
+        if self.farm is not None and self.farm.world > 1 and not keep1 and not keep2:
+            first, last = self._anchors_distributed()
+        elif use_frontier and _is_native(self.dh.pipe) and not keep1 and not keep2 \
+                and self.branch1_crossfeed_power == 0.0:
             first, last = self._compute_anchors_batched()
         else:
             first = self.tree_latents[0] if keep1 else self.compute_latents1()
@@ -377,7 +385,6 @@ class BlendingEngine:
     def _grow_level_frontier(self, idx_injection: int, stems: int):
         """Commit ``stems`` branches at this level, evaluating up to ``frontier_width`` gap
         children per round in one batch.  Commit order == the sequential greedy order."""
-        pipe = self.dh.pipe
         tree = self._tree
         ready = {}  # (fract_left, fract_right) -> (fract, trajectory, frame, sim_left, sim_right)
         remaining = stems
@@ -421,6 +428,26 @@ class BlendingEngine:
                     coeffs=planner.parental_crossfeed_coeffs(
                         self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
                         self.parental_crossfeed_range, self.parental_crossfeed_decay)))
+            if self.farm is not None and self.farm.world > 1:
+                mine = self._evaluate_specs(specs[self.farm.rank::self.farm.world], idx_injection)
+                results = self.farm.exchange_branches(mine, len(specs), self.num_inference_steps - idx_injection,
+                                                      self.num_inference_steps, make_frame=self._frame_from_u8)
+            else:
+                results = self._evaluate_specs(specs, idx_injection)
+            for s, (traj, frame, sl, sr) in zip(specs, results):
+                key = (tree.fracts[s["gap"]], tree.fracts[s["gap"] + 1])
+                ready[key] = (s["fract"], traj, frame, sl, sr)
+            self.guidance_scale = self.dh.guidance_scale = specs[-1]["guidance"]
+        self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
+
+    def _evaluate_specs(self, specs, idx_injection):
+        """Trajectory, decoded frame and the two neighbour distances for every speculated gap child.
+        Native pipe: ONE batched denoising run + one batched decode + one LPIPS launch set.
+        Generic pipe: the same work spec by spec through the diffusers-style API."""
+        if not specs:
+            return []
+        tree, pipe = self._tree, self.dh.pipe
+        if _is_native(pipe):
             trajs = pipe.native_run_diffusion_batch(
                 [s["cond"] for s in specs], [s["mixed"][idx_injection - 1] for s in specs],
                 idx_injection, [s["mixed"] for s in specs], [s["coeffs"] for s in specs],
@@ -432,12 +459,51 @@ class BlendingEngine:
                 pairs.append((frame, tree.frames[s["gap"]]))
                 pairs.append((frame, tree.frames[s["gap"] + 1]))
             sims = pipe.native_frame_distances(pairs)
-            for k, (s, traj, frame) in enumerate(zip(specs, trajs, frames)):
-                key = (tree.fracts[s["gap"]], tree.fracts[s["gap"] + 1])
-                ready[key] = (s["fract"], traj, frame, sims[2 * k], sims[2 * k + 1])
-            last = specs[-1]
-            self.guidance_scale = self.dh.guidance_scale = last["guidance"]
-        self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
+            return [(t, f, sims[2 * k], sims[2 * k + 1]) for k, (t, f) in enumerate(zip(trajs, frames))]
+        out = []
+        for s in specs:
+            self.guidance_scale = self.dh.guidance_scale = s["guidance"]
+            traj = self.run_diffusion([s["cond"]], latents_start=s["mixed"][idx_injection - 1], idx_start=idx_injection,
+                                      list_latents_mixing=s["mixed"], mixing_coeffs=s["coeffs"])
+            frame = self.dh.latent2image(traj[-1])
+            out.append((traj, frame, self.get_lpips_similarity(frame, tree.frames[s["gap"]]),
+                        self.get_lpips_similarity(frame, tree.frames[s["gap"] + 1])))
+        return out
+
+    def _frame_from_u8(self, u8: torch.Tensor):
+        """uint8 [H,W,3] tensor (as exchanged between ranks) -> the pipe's frame type."""
+        if _is_native(self.dh.pipe):
+            from .native.frames import DeviceImage
+            return DeviceImage(u8)
+        return Image.fromarray(u8.cpu().numpy())
+
+    def _anchors_distributed(self):
+        """Farm mode: anchor 1 on rank 0, anchor 2 on rank 1 (when it is not crossfed from anchor 1),
+        then every rank receives both latent stacks (C1 of SURVEY.md §8e)."""
+        farm, steps = self.farm, self.num_inference_steps
+        independent = self.branch1_crossfeed_power == 0.0
+        owner2 = 1 % farm.world if independent else 0
+        first = last = None
+        if farm.rank == 0:
+            first = self.compute_latents1()
+        elif independent and farm.rank == owner2:
+            self._skip_noise_draws(steps)            # keep a shared noise tape aligned with a serial run
+        if farm.rank == owner2:
+            if not independent:
+                self.tree_latents[0] = first
+            last = self.compute_latents2()
+        first = farm.share_trajectory(first, 0, steps)
+        last = farm.share_trajectory(last, owner2, steps)
+        self.tree_latents[0], self.tree_latents[-1] = first, last
+        return first, last
+
+    def _skip_noise_draws(self, n):
+        sched = getattr(self.dh.pipe, "scheduler", None)
+        src = getattr(sched, "noise_source", None)
+        if src is not None and getattr(sched, "ancestral", False):
+            shape = (1, self.dh.pipe.unet.config.in_channels, self.dh.height_latent, self.dh.width_latent)
+            for _ in range(n):
+                src(shape)
 
     # ------------------------------------------------------------------ plumbing ----------
     def get_noise(self, seed):

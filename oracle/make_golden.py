@@ -203,6 +203,12 @@ def tree_fixture(ref):
             "tree_fracts": [float(f) for f in be.tree_fracts], "tree_idx_injection": [int(i) for i in be.tree_idx_injection],
             "tree_similarities": [float(s) for s in be.tree_similarities],
             "final_latent_sha": [sha(l[-1]) for l in be.tree_latents], "frame_sha": [sha(i) for i in imgs],
+            # numeric summaries (compared with a tolerance: CPU conv/GEMM summation order depends on
+            # the thread count and ISA of the machine that runs the test)
+            "final_latent_head": [[float(v) for v in l[-1].flatten()[:24].float()] for l in be.tree_latents],
+            "final_latent_norm": [float(l[-1].float().norm()) for l in be.tree_latents],
+            "frame_mean": [float(np.asarray(i).mean()) for i in imgs],
+            "frame_head": [[int(v) for v in np.asarray(i).flatten()[:24]] for i in imgs],
             "none_pattern": [[x is None for x in l] for l in be.tree_latents],
         })
     return runs
