@@ -8,8 +8,12 @@ slerp, LPIPS and scheduler step executed by the gfx950 kernels of liblbhip.so (r
 programs replayed as hipGraphs; ``--frontier`` gaps evaluated per batched launch).  Weights are
 seeded synthetic SDXL-shaped tensors (no checkpoints offline), conditioning is synthetic.
 
-N > 1 (``torchrun``): one process per GPU over RCCL; every rank renders independent transitions of
-the same configuration (replicas; the branch farm is exercised by tests/test_dist_cpu.py).
+N > 1 (``torchrun``): one process per GPU, ``torch.distributed`` backend nccl (= RCCL over xGMI).  ONE
+transition tree is farmed over the ranks (latentblending_amd/dist/farm.py): anchors on ranks 0/1 and
+all-gathered, every speculative round's branches split over the ranks, latent stacks + decoded
+frames + LPIPS scalars all-gathered, identical greedy commits everywhere.  Per-GPU work is held
+fixed (weak scaling): nmb_max_branches = 15 x N  ->  15N + 2 frames per transition; `value` is the
+whole job's frames/s.
 
 The JSON line also carries
   roofline      — the dominant kernel family (MFMA GEMM / implicit-GEMM conv): algorithmic FLOPs
@@ -140,10 +144,15 @@ def main():
                             device=f"cuda:{local_rank}")
     if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
         del unet_w, vae_w
-    be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+    farm = None
+    if world > 1:
+        from latentblending_amd.dist import BranchFarm
+        farm = BranchFarm(device=torch.device("cuda", local_rank))
+    be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier * world, verbose=False,
+                        farm=farm)
     be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
     be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
-    be.set_branching(nmb_max_branches=args.branches)
+    be.set_branching(nmb_max_branches=args.branches * world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,13 +162,13 @@ def main():
 
     frames = 0
     for _ in range(args.warmup):
-        frames = len(be.run_transition(fixed_seeds=[420 + rank, 421 + rank]))
+        frames = len(be.run_transition(fixed_seeds=[420, 421]))
     for k in pipe.stats:
         pipe.stats[k] = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        frames = len(be.run_transition(fixed_seeds=[420 + rank, 421 + rank]))
+        frames = len(be.run_transition(fixed_seeds=[420, 421]))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -170,16 +179,18 @@ def main():
 
     out = {
         "metric": "transition frames/sec, SDXL-Turbo 512x512 4-step 15-branch",
-        "value": frames * args.steps * world / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "value": frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": "SDXL-Turbo 512x512, num_inference_steps=4, nmb_max_branches=%d (%d frames/transition), "
-                               "fp16, fixed_seeds=[420,421], anchors not recycled" % (args.branches, frames),
+                               "fp16, fixed_seeds=[420,421], anchors not recycled" % (args.branches * world, frames),
                    "frontier_width": args.frontier, "hipgraphs": not args.no_graphs,
-                   "parallelism": "replicas x%d" % world if world > 1 else "single GPU",
+                   "parallelism": ("branch farm over %d ranks (RCCL all-gather of anchors / branches)" % world)
+                   if world > 1 else "single GPU",
+                   "farm": None if farm is None else {"collectives": farm.collectives, "bytes_moved": farm.bytes_moved},
                    "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1)},
     }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:      # (needs a solo transition: no collectives)
         # launches of every (program, batch) per transition: one more transition with counting wrappers
         step_launch_counts = {}
         for key, prog in pipe._unet_programs.items():

@@ -244,3 +244,82 @@ def test_full_size_sdxl_unet_and_vae(results_log):
     results_log["vae_full_L64"] = {"rel_l2": rv, "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean())}
     print(f"[parity] FULL SDXL VAE 512^2: rel_l2={rv:.3e} mean|du8|={d.mean():.3f} within4={(d <= 4).mean():.4f}")
     assert rv <= 1e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99
+
+
+def test_reference_script_flow_through_shims(tmp_path, monkeypatch):
+    """The statements of the reference's example_single_trans.py (same imports, same calls) run
+    against ./diffusers (facade) and ./latentblending (shim); tiny model for speed."""
+    import importlib
+    import sys
+    monkeypatch.setenv("LB_TINY_MODEL", "1")
+    monkeypatch.chdir(tmp_path)
+    for m in [k for k in sys.modules if k == "diffusers" or k.startswith("diffusers.")]:
+        del sys.modules[m]
+    from diffusers import AutoPipelineForText2Image
+    from latentblending.blending_engine import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    set_backend(None)
+    pipe = AutoPipelineForText2Image.from_pretrained("stabilityai/sdxl-turbo", torch_dtype=torch.float16, variant="fp16")
+    pipe.to("cuda")
+    be = BlendingEngine(pipe)
+    be.set_dimensions((128, 128))
+    be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+    be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+    be.set_negative_prompt("blurry, ugly, pale")
+    frames = be.run_transition()
+    assert len(frames) == 12 and all(f.size == (128, 128) for f in frames)      # turbo default: 10 mid branches
+    be.write_movie_transition("movie_example1.mp4", duration_transition=2)
+    blob = open(tmp_path / "movie_example1.mp4", "rb").read()
+    assert blob[:4] == b"RIFF" and len(blob) > 10000
+    be.write_imgs_transition(str(tmp_path / "imgs"))
+    assert len(os.listdir(tmp_path / "imgs")) == 12
+    # multi-transition chain (example_multi_trans.py:39-58): swap_forward + recycle_img1
+    calls = pipe.stats["unet_samples"]
+    be.swap_forward()
+    be.set_prompt2("ultra high res psychedelic skyscraper city landscape")
+    frames2 = be.run_transition(recycle_img1=True, fixed_seeds=[5, 6])
+    assert len(frames2) == 12
+    assert pipe.stats["unet_samples"] - calls == 4 + 10 * 2                      # one anchor recycled
+
+
+def test_branch_farm_on_rccl_world1(results_log):
+    """The farm's collectives on the real backend (nccl == RCCL) with a single rank: API / dtype /
+    device plumbing of all-gather on device tensors; the tree must equal the farm-less run."""
+    import socket
+    import torch.distributed as dist
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    set_backend(None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        _, p, tape = make_pair(turbo=True)
+
+        def run(farm):
+            np.random.seed(0)
+            be = BlendingEngine(p, verbose=False, frontier_width=4, farm=farm)
+            be.set_dimensions((128, 128))
+            be.set_branching(nmb_max_branches=5)
+            be.set_prompt1("a")
+            be.set_prompt2("b")
+            tape.reset()
+            return be, be.run_transition(fixed_seeds=[1, 2])
+        farm = BranchFarm(device=torch.device("cuda", 0))
+        farm.world_override = None
+        be_a, ia = run(None)
+        # exercise the exchange path even at world size 1
+        farm_world = farm.world
+        be_b, ib = run(farm)
+        assert be_a.tree_fracts == be_b.tree_fracts
+        t = farm.share_trajectory(be_a.tree_latents[0], 0, 4)
+        assert all(torch.equal(a, b.reshape(a.shape)) for a, b in zip(t, be_a.tree_latents[0]))
+        res = farm.exchange_branches([(be_a.tree_latents[1], ia[1], 0.25, 0.5)], 1, 2, 4, make_frame=be_a._frame_from_u8)
+        assert res[0][2:] == (0.25, 0.5) and torch.equal(res[0][0][-1], be_a.tree_latents[1][-1])
+        assert np.array_equal(np.asarray(res[0][1]), np.asarray(ia[1]))
+        results_log["farm_rccl_world1"] = {"collectives": farm.collectives, "bytes": farm.bytes_moved}
+    finally:
+        dist.destroy_process_group()
