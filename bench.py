@@ -123,6 +123,18 @@ def cpu_baseline(unet_w, vae_w):
 
 
 def main():
+    # the host layer prints progress lines like the reference does; keep stdout for the ONE JSON line
+    real_stdout = sys.stdout
+    sys.stdout = sys.stderr
+    try:
+        out = _run()
+    finally:
+        sys.stdout = real_stdout
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def _run():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -226,10 +238,9 @@ def main():
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet_w, vae_w)
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":
