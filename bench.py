@@ -144,18 +144,17 @@ def _run():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from oracle import sdxl_ref as R           # weights shared with the cpu_baseline leg only
     import latentblending_amd.native as N
     from latentblending_amd import BlendingEngine
 
+    # seeded synthetic SDXL weights from the product's own provider; rank 0 keeps the fp32 copies so
+    # that the cpu_baseline leg can time the oracle on exactly the same parameters
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     t0 = time.perf_counter()
-    unet_w = R.make_weights(R.unet_spec(R.UNetCfg(sample_size=64)), 0)
-    vae_w = R.make_weights(R.vae_decoder_spec(R.VAECfg()), 1)
+    unet_prov, vae_prov = N.SyntheticProvider(0, keep=want_cpu), N.SyntheticProvider(1, keep=want_cpu)
+    pipe = N.NativeSDXLPipe(turbo=True, unet_provider=unet_prov, vae_provider=vae_prov, device=f"cuda:{local_rank}")
     t_weights = time.perf_counter() - t0
-    pipe = N.NativeSDXLPipe(turbo=True, unet_provider=N.DictProvider(unet_w), vae_provider=N.DictProvider(vae_w),
-                            device=f"cuda:{local_rank}")
-    if not (rank == 0 and world == 1 and not args.no_cpu_baseline):
-        del unet_w, vae_w
+    unet_w, vae_w = unet_prov.state, vae_prov.state
     farm = None
     if world > 1:
         from latentblending_amd.dist import BranchFarm
@@ -188,6 +187,9 @@ def _run():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     per_transition = {k: v / max(args.steps, 1) for k, v in census(pipe).items()}
+    n_runs = max(args.steps + args.warmup, 1)
+    per_transition["frontier_rounds"] = be.stats.get("frontier_rounds", 0) / n_runs
+    per_transition["speculation_dropped"] = be.stats.get("speculation_dropped", 0) / n_runs
 
     out = {
         "metric": "transition frames/sec, SDXL-Turbo 512x512 4-step 15-branch",

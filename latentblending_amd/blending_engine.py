@@ -73,6 +73,7 @@ class BlendingEngine:
         self.mid_compression_scaler = mid_compression_scaler
         self.frontier_width = int(frontier_width)
         self.farm = farm
+        self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.seed1 = 0
         self.seed2 = 0
         self.prompt1 = ""
@@ -383,10 +384,19 @@ class BlendingEngine:
 
     # speculative frontier (native pipes) ---------------------------------------------------
     def _grow_level_frontier(self, idx_injection: int, stems: int):
-        """Commit ``stems`` branches at this level, evaluating up to ``frontier_width`` gap
-        children per round in one batch.  Commit order == the sequential greedy order."""
+        """Commit ``stems`` branches at this level.  Each round evaluates up to ``frontier_width`` gap
+        children in one batch, chosen best-first over the REAL gaps of the tree and the VIRTUAL gaps
+        that will exist once an already evaluated (or just picked) child is committed — so the early
+        rounds of the binary splitting run full batches instead of 1, 2, 4 branches.
+
+        Exactness: a gap (left fraction, right fraction) has exactly one possible child — its midpoint,
+        mixed from the parents of the enclosing real gap (same-level nodes are never parents) — and its
+        distances to the gap's two end frames do not depend on anything else.  Evaluated children wait
+        in ``ready`` until the reference's greedy order asks for their gap; whatever is never asked
+        for is dropped at the end of the level."""
+        import heapq
         tree = self._tree
-        ready = {}  # (fract_left, fract_right) -> (fract, trajectory, frame, sim_left, sim_right)
+        ready = {}                    # (f_left, f_right) -> dict(fract, traj, frame, sl, sr)
         remaining = stems
         while remaining > 0:
             # 1) commit everything the greedy order can already consume
@@ -396,57 +406,78 @@ class BlendingEngine:
                 gap = tree.widest_gap()
                 key = (tree.fracts[gap], tree.fracts[gap + 1])
                 if key in ready:
-                    fract, traj, frame, sl, sr = ready.pop(key)
-                    tree.commit(fract, idx_injection, traj, frame, sl, sr)
+                    r = ready.pop(key)
+                    tree.commit(r["fract"], idx_injection, r["traj"], r["frame"], r["sl"], r["sr"])
                     remaining -= 1
                     progressed = True
             if remaining == 0:
                 break
-            # 2) speculate: the widest not-yet-evaluated gaps
-            if any(s is UNSCORED for s in tree.similarities):
-                order = [tree.widest_gap()]
-            else:  # descending, first maximum first (np.argmax tie-break)
-                order = list(np.argsort(-np.asarray(tree.similarities, dtype=np.float64),
-                                        kind="stable"))
-            picks = []
-            for gap in order:
-                key = (tree.fracts[int(gap)], tree.fracts[int(gap) + 1])
-                if key not in ready:
-                    picks.append(int(gap))
-                if len(picks) >= min(self.frontier_width, remaining):
-                    break
+            # 2) pick what to evaluate next: best-first over real + virtual gaps
+            heap, tick = [], 0
+            unscored = any(s is UNSCORED for s in tree.similarities)
+            for g in range(len(tree.fracts) - 1):
+                est = float("inf") if unscored else float(tree.similarities[g])
+                heap.append((-est, tick, tree.fracts[g], tree.fracts[g + 1], g))
+                tick += 1
+            heapq.heapify(heap)
+            budget = min(self.frontier_width, max(1, remaining - len(ready)))
             specs = []
-            for gap in picks:
-                fract, p1, p2 = tree.gap_child(gap, idx_injection)
-                g_eff = planner.damped_guidance(self.guidance_scale_base,
-                                                self.guidance_scale_mid_damper, fract)
-                f1, f2 = tree.fracts[p1], tree.fracts[p2]
-                specs.append(dict(
-                    gap=gap, fract=fract, guidance=g_eff,
-                    cond=self.get_mixed_conditioning(fract)[0],
-                    mixed=self._parental_mix(p1, p2, (fract - f1) / (f2 - f1)),
-                    coeffs=planner.parental_crossfeed_coeffs(
-                        self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
-                        self.parental_crossfeed_range, self.parental_crossfeed_decay)))
+            while heap and len(specs) < budget:
+                neg_est, _, fl, fr, g = heapq.heappop(heap)
+                mid = (fl + fr) / 2
+                if (fl, fr) in ready:                      # child known: its halves have exact distances
+                    est_l, est_r = ready[(fl, fr)]["sl"], ready[(fl, fr)]["sr"]
+                else:
+                    _, p1, p2 = tree.gap_child(g, idx_injection)
+                    f1, f2 = tree.fracts[p1], tree.fracts[p2]
+                    specs.append(dict(
+                        gap=g, left=fl, right=fr, fract=mid,
+                        guidance=planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper, mid),
+                        cond=self.get_mixed_conditioning(mid)[0],
+                        mixed=self._parental_mix(p1, p2, (mid - f1) / (f2 - f1)),
+                        coeffs=planner.parental_crossfeed_coeffs(
+                            self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
+                            self.parental_crossfeed_range, self.parental_crossfeed_decay)))
+                    est_l = est_r = -neg_est / 2           # heuristic until the child exists
+                if self.speculate_virtual:
+                    for a, b, e in ((fl, mid, est_l), (mid, fr, est_r)):
+                        heapq.heappush(heap, (-float(e), tick, a, b, g))
+                        tick += 1
+            # 3) evaluate (batched on a native pipe, split over the ranks of a farm), then score
             if self.farm is not None and self.farm.world > 1:
                 mine = self._evaluate_specs(specs[self.farm.rank::self.farm.world], idx_injection)
-                results = self.farm.exchange_branches(mine, len(specs), self.num_inference_steps - idx_injection,
+                results = self.farm.exchange_branches([(t, f, 0.0, 0.0) for t, f in mine], len(specs),
+                                                      self.num_inference_steps - idx_injection,
                                                       self.num_inference_steps, make_frame=self._frame_from_u8)
+                results = [(t, f) for t, f, _, _ in results]
             else:
                 results = self._evaluate_specs(specs, idx_injection)
-            for s, (traj, frame, sl, sr) in zip(specs, results):
-                key = (tree.fracts[s["gap"]], tree.fracts[s["gap"] + 1])
-                ready[key] = (s["fract"], traj, frame, sl, sr)
+            frame_at = {f: tree.frames[i] for i, f in enumerate(tree.fracts)}
+            frame_at.update({r["fract"]: r["frame"] for r in ready.values()})
+            frame_at.update({s["fract"]: fr_ for s, (_, fr_) in zip(specs, results)})
+            pairs = []
+            for s, (_, frame) in zip(specs, results):
+                pairs += [(frame, frame_at[s["left"]]), (frame, frame_at[s["right"]])]
+            sims = self._frame_distances(pairs)
+            for k, (s, (traj, frame)) in enumerate(zip(specs, results)):
+                ready[(s["left"], s["right"])] = dict(fract=s["fract"], traj=traj, frame=frame,
+                                                      sl=sims[2 * k], sr=sims[2 * k + 1])
             self.guidance_scale = self.dh.guidance_scale = specs[-1]["guidance"]
+            self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
         self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
 
+    def _frame_distances(self, pairs):
+        pipe = self.dh.pipe
+        if _is_native(pipe) and self.lpips is getattr(pipe, "lpips_metric", None):
+            return pipe.native_frame_distances(pairs) if pairs else []
+        return [self.get_lpips_similarity(a, b) for a, b in pairs]
+
     def _evaluate_specs(self, specs, idx_injection):
-        """Trajectory, decoded frame and the two neighbour distances for every speculated gap child.
-        Native pipe: ONE batched denoising run + one batched decode + one LPIPS launch set.
-        Generic pipe: the same work spec by spec through the diffusers-style API."""
+        """(trajectory, decoded frame) for every speculated gap child.  Native pipe: ONE batched
+        denoising run + one batched decode.  Generic pipe: spec by spec through the diffusers-style API."""
         if not specs:
             return []
-        tree, pipe = self._tree, self.dh.pipe
+        pipe = self.dh.pipe
         if _is_native(pipe):
             trajs = pipe.native_run_diffusion_batch(
                 [s["cond"] for s in specs], [s["mixed"][idx_injection - 1] for s in specs],
@@ -454,20 +485,13 @@ class BlendingEngine:
                 num_inference_steps=self.num_inference_steps,
                 guidance_scales=[s["guidance"] for s in specs])
             frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil")
-            pairs = []
-            for s, frame in zip(specs, frames):
-                pairs.append((frame, tree.frames[s["gap"]]))
-                pairs.append((frame, tree.frames[s["gap"] + 1]))
-            sims = pipe.native_frame_distances(pairs)
-            return [(t, f, sims[2 * k], sims[2 * k + 1]) for k, (t, f) in enumerate(zip(trajs, frames))]
+            return list(zip(trajs, frames))
         out = []
         for s in specs:
             self.guidance_scale = self.dh.guidance_scale = s["guidance"]
             traj = self.run_diffusion([s["cond"]], latents_start=s["mixed"][idx_injection - 1], idx_start=idx_injection,
                                       list_latents_mixing=s["mixed"], mixing_coeffs=s["coeffs"])
-            frame = self.dh.latent2image(traj[-1])
-            out.append((traj, frame, self.get_lpips_similarity(frame, tree.frames[s["gap"]]),
-                        self.get_lpips_similarity(frame, tree.frames[s["gap"] + 1])))
+            out.append((traj, self.dh.latent2image(traj[-1])))
         return out
 
     def _frame_from_u8(self, u8: torch.Tensor):

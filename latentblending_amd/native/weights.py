@@ -29,20 +29,29 @@ def _seeded(name: str, shape: Sequence[int], std: float, seed: int, mean: float 
 
 
 class SyntheticProvider:
-    def __init__(self, seed: int = 0):
+    def __init__(self, seed: int = 0, keep: bool = False):
+        """``keep``: remember every generated tensor in ``self.state`` (HF key -> fp32 tensor), e.g.
+        so that a benchmark can time a CPU checker on exactly the weights the device path uses."""
         self.seed = seed
+        self.state: Optional[Dict[str, torch.Tensor]] = {} if keep else None
+
+    def _out(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        t = t.half().float()
+        if self.state is not None:
+            self.state[name] = t
+        return t
 
     def weight(self, name: str, shape: Sequence[int], fan_in: int, gain: float = 1.0) -> torch.Tensor:
-        return _seeded(name, shape, gain / math.sqrt(fan_in), self.seed).half().float()
+        return self._out(name, _seeded(name, shape, gain / math.sqrt(fan_in), self.seed))
 
     def bias(self, name: str, n: int) -> torch.Tensor:
-        return _seeded(name, (n,), 0.02, self.seed).half().float()
+        return self._out(name, _seeded(name, (n,), 0.02, self.seed))
 
     def norm_weight(self, name: str, n: int) -> torch.Tensor:
-        return _seeded(name, (n,), 0.05, self.seed, mean=1.0).half().float()
+        return self._out(name, _seeded(name, (n,), 0.05, self.seed, mean=1.0))
 
     def positive(self, name: str, n: int) -> torch.Tensor:        # LPIPS lin layers (non-negative)
-        return (_seeded(name, (n,), 1.0, self.seed).abs() / n).half().float()
+        return self._out(name, _seeded(name, (n,), 1.0, self.seed).abs() / n)
 
 
 class DictProvider:
