@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed transitions")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frontier", type=int, default=8, help="gaps evaluated per batched launch")
+    ap.add_argument("--frontier", type=int, default=16, help="gap children evaluated per batched round (per GPU)")
     ap.add_argument("--branches", type=int, default=15)
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

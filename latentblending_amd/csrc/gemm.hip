@@ -58,7 +58,15 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int block_n = bid % n_blocks, block_m = bid / n_blocks;
+    // Tile order inside an XCD's contiguous run: the operand with MORE bytes must be the one that is
+    // shared.  Weight-dominated problems (N > M: every UNet GEMM at batch 1-8) walk the M blocks of
+    // a weight panel first, so each XCD streams only its own few weight panels from HBM (with the
+    // other order every XCD's L2 pulls the whole weight matrix: up to 8x redundant HBM reads);
+    // activation-dominated problems (VAE convs, M >> N) keep the A panel resident instead.
+    const int m_blocks = (p.M + BM - 1) / BM;
+    const bool w_dominant = (GEGLU ? p.N / 2 : p.N) > p.M;
+    const int block_n = w_dominant ? bid / m_blocks : bid % n_blocks;
+    const int block_m = w_dominant ? bid % m_blocks : bid / n_blocks;
     const int m0 = block_m * BM;
     const int n0 = GEGLU ? block_n * (BN / 2) : block_n * BN;
 
