@@ -91,12 +91,15 @@ typedef struct LbGemmParams {
     int ups;                 /* 1: nearest-2x upsample of the input fused into the gather */
     int ldx;                 /* pixel stride in elements (>= Cin) */
     int splitk;              /* set by the launcher */
+    const void* zero_page;   /* >= 16 zero bytes, 16-B aligned (source of masked chunks for the
+                                direct-to-LDS variant); NULL = register-ring variant only */
 } LbGemmParams;
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
 void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1/2/3 and split-K */
 void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */
+void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default) */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached
  *      from diffusers_holder.py:336 and :135) ------------------------------------------- */

@@ -344,6 +344,16 @@ static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = for
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
 extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 
+// direct-to-LDS variant (gemm_glds.hip)
+int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream);
+void lb_gemm_glds_init();
+static int g_variant = 0, g_stages = 0;
+extern "C" void lb_gemm_set_variant(int variant, int stages) {
+    g_variant = variant;
+    g_stages = stages;
+    if (variant == 1) lb_gemm_glds_init();
+}
+
 extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     // enough for the largest split the heuristic can pick (<= 16 slabs)
     return (long)16 * M * N * (long)sizeof(float);
@@ -366,11 +376,16 @@ static int default_depth(const LbGemmParams& p, int tile) {
     return 4;
 }
 
-static int gemm_launch_impl(LbGemmParams p, int tile, int depth, dim3 grid, hipStream_t stream) {
-    if (depth <= 0) depth = default_depth(p, tile);
-    if (tile == 1) launch_depth<128, 128>(p, depth, grid, stream);
-    else if (tile == 2) launch_depth<128, 64>(p, depth, grid, stream);
-    else launch_depth<64, 64>(p, depth, grid, stream);
+static int gemm_launch_impl(LbGemmParams p, int tile, int depth, int variant, int stages, dim3 grid,
+                            hipStream_t stream) {
+    if (variant == 1 && p.zero_page != nullptr) {
+        lb_gemm_launch_glds(p, tile, stages, grid, stream);
+    } else {
+        if (depth <= 0) depth = default_depth(p, tile);
+        if (tile == 1) launch_depth<128, 128>(p, depth, grid, stream);
+        else if (tile == 2) launch_depth<128, 64>(p, depth, grid, stream);
+        else launch_depth<64, 64>(p, depth, grid, stream);
+    }
     int rc = lb_check_launch("lb_gemm_f16");
     if (rc) return rc;
     if (p.splitk > 1) {
@@ -426,7 +441,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         if (splitk < 1) splitk = 1;
     }
     p.splitk = splitk;
-    const int depth = g_depth;
+    const int depth = g_depth, variant = g_variant, stages = g_stages;
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
-    LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, grid, s));
+    LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));
 }

@@ -1,0 +1,294 @@
+// Direct-to-LDS variant of the MFMA GEMM / implicit-GEMM conv (same contract as gemm.hip).
+//
+// Staging uses `global_load_lds_dwordx4`: each wave instruction moves 64 x 16 B straight from
+// global memory into 1 KiB of LDS (no VGPR round trip, no ds_write pass - the register->LDS path is
+// the narrowest pipe of the CU).  The LDS image of a tile is the same XOR-swizzled [rows][64] fp16
+// layout the fragment reads expect; because the LDS destination of the instruction is lane-linear,
+// the swizzle is applied to the per-lane GLOBAL source address instead (lane (r, s) fetches logical
+// chunk s ^ (r & 7) of row r - the 8 lanes of a row still cover one 128-B line).  Out-of-range
+// chunks (conv padding, M / N / K tails) fetch from a 16-byte zero page.
+//
+// Pipeline: S-stage LDS ring, tile t+S-1 in flight while tile t is multiplied.  Per K-tile:
+//   s_waitcnt vmcnt((S-2) * loads_per_tile)   <- this thread's part of tile t has landed
+//   s_barrier                                 <- everybody's part has landed AND everybody finished
+//                                                reading stage (t-1) % S, which is refilled next
+//   issue tile t+S-1 ; ds_read + MFMA on stage t % S
+// i.e. ONE barrier per K-tile and never a vmcnt(0) in the steady state.
+#include "lb_common.h"
+#include "lb_gemm.h"
+
+#define BK 64
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, bool CONV, bool GEGLU, int S>
+__global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p) {
+    constexpr int AI = BM * 8 / 256;        // wave instructions (16-B chunks per thread) of A per K-tile
+    constexpr int WI = BN * 8 / 256;
+    constexpr int NL = AI + WI;             // VMEM loads per thread per K-tile
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int STAGE = (BM + BN) * BK;   // halves per ring stage
+    extern __shared__ __attribute__((aligned(16))) f16 lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int g = lane >> 4, l16 = lane & 15;
+
+    const int n_blocks = GEGLU ? (p.N / 2 + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m_blocks = (p.M + BM - 1) / BM;
+    const bool w_dominant = (GEGLU ? p.N / 2 : p.N) > p.M;
+    const int block_n = w_dominant ? bid / m_blocks : bid % n_blocks;
+    const int block_m = w_dominant ? bid % m_blocks : bid / n_blocks;
+    const int m0 = block_m * BM;
+    const int n0 = GEGLU ? block_n * (BN / 2) : block_n * BN;
+
+    const int k_tiles_total = (p.K + BK - 1) / BK;
+    const int tiles_per_split = (k_tiles_total + p.splitk - 1) / p.splitk;
+    const int kt_begin = blockIdx.z * tiles_per_split;
+    int kt_end = kt_begin + tiles_per_split;
+    if (kt_end > k_tiles_total) kt_end = k_tiles_total;
+    const int nkt = kt_end - kt_begin;
+    const int k_end = kt_end * BK < p.K ? kt_end * BK : p.K;
+
+    // thread (r = tid>>3 (+32 i), s = tid&7) owns physical chunk s of tile row r and fetches logical
+    // chunk s ^ (r & 7); (r & 7) == (lane >> 3) for every i because row groups start at multiples of 8
+    const int row0 = tid >> 3;
+    const int cl = (tid & 7) ^ ((tid >> 3) & 7);     // logical chunk fetched by this lane
+
+    long a_off[AI];
+    int a_iy[AI], a_ix[AI];
+    bool a_ok[AI];
+    int ci = 0, ky = 0, kx = 0;
+    int kcur = kt_begin * BK + cl * 8;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int m = m0 + row0 + i * 32;
+        a_ok[i] = m < p.M;
+        if (CONV) {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_off[i] = (long)b * p.Hin * p.Win * p.ldx;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+        } else {
+            a_off[i] = (long)m * p.lda;
+            a_iy[i] = a_ix[i] = 0;
+        }
+    }
+    if (CONV) {
+        const int tap = kcur / p.Cin;
+        ci = kcur - tap * p.Cin;
+        ky = tap / p.KW;
+        kx = tap - ky * p.KW;
+    }
+    long w_off[WI];
+    bool w_ok[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int tr = row0 + i * 32;
+        int n;
+        if (GEGLU) {
+            const int sub = tr >> 4;
+            n = (sub & 1) * (p.N / 2) + n0 + (sub >> 1) * 16 + (tr & 15);
+            w_ok[i] = (n0 + (sub >> 1) * 16 + (tr & 15)) < p.N / 2;
+        } else {
+            n = n0 + tr;
+            w_ok[i] = n < p.N;
+        }
+        w_off[i] = (long)n * p.ldw;
+    }
+    const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
+    const int hin_eff = p.Hin << p.ups, win_eff = p.Win << p.ups;
+
+    // request one K-tile into ring stage `st` (branch-free: masked chunks read the zero page)
+    auto issue_tile = [&](int st) {
+        f16* base = lds + st * STAGE;
+        const bool k_ok = kcur < k_end;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const lb_half* src;
+            if (CONV) {
+                const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                const bool ok = a_ok[i] && k_ok && iy >= 0 && iy < hin_eff && ix >= 0 && ix < win_eff;
+                src = ok ? p.A + a_off[i] + ((long)(iy >> p.ups) * p.Win + (ix >> p.ups)) * p.ldx + ci : zero;
+            } else {
+                src = (a_ok[i] && k_ok) ? p.A + a_off[i] + kcur : zero;
+            }
+            // wave-uniform LDS base of this instruction's 8 rows; hardware adds lane * 16 B
+            f16* dst = base + (wave * 8 + i * 32) * BK;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const lb_half* src = (w_ok[i] && k_ok) ? p.W + w_off[i] + kcur : zero;
+            f16* dst = base + BM * BK + (wave * 8 + i * 32) * BK;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        }
+        kcur += BK;
+        if (CONV) {
+            ci += BK;
+            if (p.Cin >= BK) {
+                const bool wrap = ci >= p.Cin;
+                ci -= wrap ? p.Cin : 0;
+                kx += wrap ? 1 : 0;
+                const bool wrapx = kx == p.KW;
+                kx = wrapx ? 0 : kx;
+                ky += wrapx ? 1 : 0;
+            } else {
+                while (ci >= p.Cin) {
+                    ci -= p.Cin;
+                    if (++kx == p.KW) { kx = 0; ++ky; }
+                }
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int st) {
+        const f16* Ab = lds + st * STAGE + (wave_m * (BM / 2)) * BK;
+        const f16* Wb = lds + st * STAGE + BM * BK + (wave_n * (BN / 2)) * BK;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 af[TM], wf[TN];
+            const int chunk = s * 4 + g;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = i * 16 + l16;
+                af[i] = *reinterpret_cast<const f16x8*>(Ab + r * BK + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = j * 16 + l16;
+                wf[j] = *reinterpret_cast<const f16x8*>(Wb + r * BK + ((chunk ^ (r & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: tiles 0 .. S-2 in flight ----
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) issue_tile(s);
+
+    int st = 0;                               // ring stage of tile t
+    for (int t = 0; t < nkt; ++t) {
+        wait_vm_barrier<(S - 2) * NL>();      // tile t landed everywhere; stage (t-1)%S free everywhere
+        int refill = st - 1;
+        if (refill < 0) refill += S;
+        issue_tile(refill);                   // tile t+S-1 (masked to zeros past the end)
+        compute(st);
+        st = st + 1 == S ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before exit/epilogue
+
+    // ---- epilogue (identical to gemm.hip) ----
+    if (p.splitk > 1) {
+        float* slab = p.partial + (long)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wave_m * (BM / 2) + i * 16 + l16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wave_n * (BN / 2) + j * 16 + 4 * g;
+                if (n < p.N) *reinterpret_cast<f32x4*>(slab + (long)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wave_m * (BM / 2) + i * 16 + l16;
+        if (m >= p.M) continue;
+        const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
+        if (GEGLU) {
+#pragma unroll
+            for (int j = 0; j < TN; j += 2) {
+                const int n = n0 + (wave_n * (BN / 64) + (j >> 1)) * 16 + 4 * g;
+                if (n >= p.N / 2) continue;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float h = acc[i][j][r] * p.alpha, gt = acc[i][j + 1][r] * p.alpha;
+                    if (p.bias) { h += p.bias[n + r]; gt += p.bias[p.N / 2 + n + r]; }
+                    o[r] = (f16)(h * lb_gelu_erf(gt));
+                }
+                *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wave_n * (BN / 2) + j * 16 + 4 * g;
+                if (n >= p.N) continue;
+                lb_gemm_store4(p, m, n, bidx, acc[i][j]);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int S>
+static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+    const size_t smem = (size_t)S * (BM + BN) * BK * sizeof(f16);
+    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
+    if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S>), grid, dim3(256), smem, stream, p);
+    else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S>), grid, dim3(256), smem, stream, p);
+    else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S>), grid, dim3(256), smem, stream, p);
+    return 0;
+}
+
+// dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside of any stream capture
+template <int BM, int BN, int S>
+static void allow_lds() {
+    const int smem = S * (BM + BN) * BK * (int)sizeof(f16);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+
+void lb_gemm_glds_init() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    allow_lds<128, 128, 2>(); allow_lds<128, 128, 3>();
+    allow_lds<128, 64, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
+    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3>(); allow_lds<64, 64, 4>();
+}
+
+// tile: 1 = 128x128, 3 = 64x64 ; stages: 2..4 (0 = default for the tile)
+int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
+    if (tile == 1) {
+        if (stages == 2) return launch_glds_variant<128, 128, 2>(p, grid, stream);
+        return launch_glds_variant<128, 128, 3>(p, grid, stream);
+    }
+    if (tile == 2) {
+        if (stages == 2) return launch_glds_variant<128, 64, 2>(p, grid, stream);
+        if (stages == 4) return launch_glds_variant<128, 64, 4>(p, grid, stream);
+        return launch_glds_variant<128, 64, 3>(p, grid, stream);
+    }
+    if (stages == 2) return launch_glds_variant<64, 64, 2>(p, grid, stream);
+    if (stages == 3) return launch_glds_variant<64, 64, 3>(p, grid, stream);
+    return launch_glds_variant<64, 64, 4>(p, grid, stream);
+}

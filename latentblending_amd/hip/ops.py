@@ -156,6 +156,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     if rowvec is not None:
         p.ld_rowvec, p.rows_per_batch = rowvec.stride(0), rows_per_batch
     p.alpha, p.flags = alpha, flags
+    zp = torch.zeros(64, dtype=torch.uint8, device=dev)
+    p.zero_page = zp.data_ptr()
     ws = None
     if splitk_ws and not (flags & lib.GEMM_GEGLU):
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)

@@ -136,6 +136,7 @@ class Emitter:
         self.gemm_log: List[dict] = []
         self.attn_log: List[dict] = []
         self._retired: List[torch.Tensor] = []
+        self.zero_page = torch.zeros(64, dtype=torch.uint8, device=self.device)
 
     # -- workspaces -------------------------------------------------------------------------
     def _gemm_ws(self, M: int, N: int) -> Optional[torch.Tensor]:
@@ -181,6 +182,7 @@ class Emitter:
         if rowvec is not None:
             p.ld_rowvec, p.rows_per_batch = ld_rowvec if ld_rowvec is not None else N, rows_per_batch
         p.alpha, p.flags = alpha, flags
+        p.zero_page = self.zero_page.data_ptr()
         if splitk and not (flags & lib.GEMM_GEGLU):
             p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())

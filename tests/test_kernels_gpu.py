@@ -424,3 +424,53 @@ def test_small_kernels(results_log):
     ref = F.max_pool2d(f.float(), 3, 2).permute(0, 2, 3, 1)
     got = o.maxpool3s2(f.permute(0, 2, 3, 1).contiguous().to(DEV))
     assert torch.equal(got.cpu().float(), ref)
+
+
+# ------------------------------------------------------------------ direct-to-LDS GEMM variant
+@pytest.mark.parametrize("stages", [2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_glds_variant(tile, stages, results_log):
+    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references."""
+    o, l = ops(), lib()
+    l.api.lb_gemm_set_variant(1, stages)
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        for (M, N, K) in [(256, 1280, 1280), (100, 64, 72), (333, 132, 200), (2048, 640, 2560), (77, 1280, 2048)]:
+            A, W = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=K ** -0.5)
+            bias, res = rnd(N, seed=73, dtype=torch.float32), rnd(M, N, seed=74)
+            ref = A.float() @ W.float().t() + bias + res.float()
+            got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+            check_close(results_log, f"glds_gemm_{M}x{N}x{K}_t{tile}s{stages}", got, ref)
+        # GEGLU
+        M, C = 300, 640
+        A, W = rnd(M, C, seed=75), rnd(8 * C, C, seed=76, scale=C ** -0.5)
+        bias = rnd(8 * C, seed=77, dtype=torch.float32, scale=0.1)
+        h, gate = (A.float() @ W.float().t() + bias).chunk(2, dim=-1)
+        got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_GEGLU)
+        check_close(results_log, f"glds_geglu_t{tile}s{stages}", got, h * F.gelu(gate))
+        # split-K
+        l.api.lb_gemm_set_tuning(tile, 5)
+        A, W = rnd(256, 5120, seed=78), rnd(1280, 5120, seed=79, scale=5120 ** -0.5)
+        got = o.gemm(A.to(DEV), W.to(DEV))
+        check_close(results_log, f"glds_splitk_t{tile}s{stages}", got, A.float() @ W.float().t())
+        l.api.lb_gemm_set_tuning(tile, 0)
+        # convolutions incl. padding / stride / upsample / tiny Cin
+        for case in CONV_CASES:
+            B, H, Wd, Cin, Cout, k, st, pad, ups = case
+            x = rnd(B, Cin, H, Wd, seed=80)
+            w = rnd(Cout, Cin, k, k, seed=81, scale=(Cin * k * k) ** -0.5)
+            b = rnd(Cout, seed=82, dtype=torch.float32)
+            xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+            ref = F.conv2d(xin, w.float(), b, stride=st, padding=pad).permute(0, 2, 3, 1)
+            cin_p, cout_p = (Cin + 7) // 8 * 8, (Cout + 3) // 4 * 4
+            xn = torch.zeros(B, H, Wd, cin_p, dtype=torch.float16)
+            xn[..., :Cin] = x.permute(0, 2, 3, 1)
+            wp = torch.zeros(cout_p, k * k * cin_p, dtype=torch.float16)
+            wp[:Cout] = o.pack_conv_weight(w, cin_p)
+            bp = torch.zeros(cout_p, dtype=torch.float32)
+            bp[:Cout] = b
+            got = o.gemm(xn.to(DEV), wp.to(DEV), bias=bp.to(DEV), conv=dict(KH=k, KW=k, stride=st, pad=pad, ups=ups))
+            check_close(results_log, f"glds_conv_{'_'.join(map(str, case))}_t{tile}s{stages}", got[..., :Cout], ref)
+    finally:
+        l.api.lb_gemm_set_variant(0, 0)
+        l.api.lb_gemm_set_tuning(0, 0)

@@ -13,9 +13,10 @@ from latentblending_amd.native.runtime import Program
 DEV, REP = "cuda", 20
 
 
-def time_variant(p, tile, depth, splitk):
+def time_variant(p, tile, depth, splitk, glds_stages=0):
     lib.api.lb_gemm_set_tuning(tile, splitk)
     lib.api.lb_gemm_set_depth(depth)
+    lib.api.lb_gemm_set_variant(1 if glds_stages else 0, glds_stages)
     prog = Program("sweep")
     try:
         with prog.record():
@@ -24,6 +25,7 @@ def time_variant(p, tile, depth, splitk):
     finally:
         lib.api.lb_gemm_set_tuning(0, 0)
         lib.api.lb_gemm_set_depth(0)
+        lib.api.lb_gemm_set_variant(0, 0)
     prog.instantiate()
     st = torch.cuda.current_stream().cuda_stream
     prog.launch(st)
@@ -39,7 +41,7 @@ def time_variant(p, tile, depth, splitk):
 
 def main():
     shapes = []
-    for B in (1, 2, 8):
+    for B in (2, 15):
         M3, M2 = 256 * B, 1024 * B
         shapes += [("lin", M3, 1280, 1280), ("lin", M3, 2560, 1280), ("lin", M3, 1280, 5120), ("geglu", M3, 10240, 1280),
                    ("lin", 1280, M3, 1280), ("lin", M2, 640, 640), ("geglu", M2, 5120, 640), ("lin", M2, 640, 2560),
@@ -74,12 +76,16 @@ def main():
         small = ((M + 63) // 64) * ((N + 63) // 64) < 160
         best = None
         row = {"shape": tag, "variants": {}}
+        zp = torch.zeros(64, dtype=torch.uint8, device=DEV)
+        p.zero_page = zp.data_ptr()
         for tile in (1, 2, 3):
-            for depth in (1, 2, 3, 4):
-                for sk in ([0] if not small or sh[0] == "geglu" else [1, 0, 4, 8]):
+            for mode, val in [("d", 1), ("d", 3), ("d", 4), ("g", 2), ("g", 3), ("g", 4)]:
+                if tile == 1 and mode == "g" and val == 4:
+                    continue
+                for sk in ([0] if not small or sh[0] == "geglu" else [1, 0]):
                     p.partial = ws.data_ptr() if (small and sh[0] != "geglu" and sk != 1) else None
-                    us = time_variant(p, tile, depth, 0 if sk in (0, 1) else sk)
-                    key = f"t{tile}d{depth}k{sk}"
+                    us = time_variant(p, tile, val if mode == "d" else 0, 0, val if mode == "g" else 0)
+                    key = f"t{tile}{mode}{val}k{sk}"
                     row["variants"][key] = us
                     if best is None or us < best[1]:
                         best = (key, us)
