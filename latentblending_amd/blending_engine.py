@@ -74,6 +74,7 @@ class BlendingEngine:
         self.frontier_width = int(frontier_width)
         self.farm = farm
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
+        self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
         self.seed1 = 0
         self.seed2 = 0
         self.prompt1 = ""
@@ -265,7 +266,14 @@ class BlendingEngine:
         use_frontier = self.frontier_width > 1 or self.farm is not None
         keep1 = recycle_img1 and len(self.tree_latents[0]) == steps
         keep2 = recycle_img2 and len(self.tree_latents[-1]) == steps
-        if self.farm is not None and self.farm.world > 1 and not keep1 and not keep2:
+        prefilled = None
+        fuse = (use_frontier and self.fuse_anchor_round and self.farm is None and _is_native(self.dh.pipe)
+                and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0 and self.speculate_virtual
+                and len(self.list_idx_injection) == 1 and int(self.list_idx_injection[0]) >= 1
+                and int(self.list_nmb_stems[0]) >= 1)
+        if fuse:
+            first, last, prefilled = self._anchors_with_first_round()
+        elif self.farm is not None and self.farm.world > 1 and not keep1 and not keep2:
             first, last = self._anchors_distributed()
         elif use_frontier and _is_native(self.dh.pipe) and not keep1 and not keep2 \
                 and self.branch1_crossfeed_power == 0.0:
@@ -274,14 +282,16 @@ class BlendingEngine:
             first = self.tree_latents[0] if keep1 else self.compute_latents1()
             last = self.tree_latents[-1] if keep2 else self.compute_latents2()
 
-        frames = self._decode_many([first[-1], last[-1]])
-        self._tree.reset(first, last, frames[0], frames[1])
+        if prefilled is None:
+            frames = self._decode_many([first[-1], last[-1]])
+            self._tree.reset(first, last, frames[0], frames[1])
 
         for level in tqdm(range(len(self.list_idx_injection)), disable=not self.verbose):
             stems = int(self.list_nmb_stems[level])
             idx_injection = int(self.list_idx_injection[level])
             if use_frontier:
-                self._grow_level_frontier(idx_injection, stems)
+                self._grow_level_frontier(idx_injection, stems, ready=prefilled)
+                prefilled = None
             else:
                 for _ in range(stems):
                     fract, p1, p2 = self.get_mixing_parameters(idx_injection)
@@ -383,7 +393,55 @@ class BlendingEngine:
         return [self.dh.latent2image(z) for z in latents]
 
     # speculative frontier (native pipes) ---------------------------------------------------
-    def _grow_level_frontier(self, idx_injection: int, stems: int):
+    @staticmethod
+    def _bfs_midpoints(count: int):
+        """(left, right, mid) of the first ``count`` gaps of [0,1] in level order — the order in which the
+        best-first speculation visits gaps while no distance is known yet."""
+        out, level = [], [(0.0, 1.0)]
+        while len(out) < count:
+            nxt = []
+            for fl, fr in level:
+                if len(out) < count:
+                    out.append((fl, fr, (fl + fr) / 2))
+                nxt += [(fl, (fl + fr) / 2), ((fl + fr) / 2, fr)]
+            level = nxt
+        return out
+
+    def _anchors_with_first_round(self):
+        """Single-level trees on a native pipe: every mid branch mixes the two ANCHORS, and at step i
+        it only needs their latents of step i-1.  So the first speculative round (level-order
+        midpoints, exactly what the best-first frontier would pick before any distance is known) is
+        denoised in the same UNet batches as the anchors' own steps >= idx_injection, all frames
+        are decoded in one batch, and the greedy loop then starts from a pre-filled pool."""
+        pipe, steps = self.dh.pipe, self.num_inference_steps
+        idx_injection, stems = int(self.list_idx_injection[0]), int(self.list_nmb_stems[0])
+        t0 = time.time()
+        self.dh.set_num_inference_steps(steps)
+        gaps = self._bfs_midpoints(min(self.frontier_width, stems))
+        coeffs = planner.parental_crossfeed_coeffs(steps, idx_injection, self.parental_crossfeed_power,
+                                                   self.parental_crossfeed_range, self.parental_crossfeed_decay)
+        guid = [planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper, m) for _, _, m in gaps]
+        first, last, mids = pipe.native_run_wavefront(
+            [self.get_mixed_conditioning(0)[0], self.get_mixed_conditioning(1)[0]],
+            [self.get_noise(self.seed1), self.get_noise(self.seed2)],
+            [self.get_mixed_conditioning(m)[0] for _, _, m in gaps], [m for _, _, m in gaps],
+            [coeffs] * len(gaps), idx_injection, steps, self.guidance_scale, guid)
+        self.dt_unet_step = (time.time() - t0) / steps
+        frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
+        self._tree.reset(first, last, frames[0], frames[1])
+        frame_at = {0.0: frames[0], 1.0: frames[1]}
+        frame_at.update({m: f for (_, _, m), f in zip(gaps, frames[2:])})
+        pairs = []
+        for (fl, fr, m) in gaps:
+            pairs += [(frame_at[m], frame_at[fl]), (frame_at[m], frame_at[fr])]
+        sims = self._frame_distances(pairs)
+        ready = {(fl, fr): dict(fract=m, traj=traj, frame=frame_at[m], sl=sims[2 * k], sr=sims[2 * k + 1])
+                 for k, ((fl, fr, m), traj) in enumerate(zip(gaps, mids))}
+        self.guidance_scale = self.dh.guidance_scale = guid[-1]
+        self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
+        return first, last, ready
+
+    def _grow_level_frontier(self, idx_injection: int, stems: int, ready=None):
         """Commit ``stems`` branches at this level.  Each round evaluates up to ``frontier_width`` gap
         children in one batch, chosen best-first over the REAL gaps of the tree and the VIRTUAL gaps
         that will exist once an already evaluated (or just picked) child is committed — so the early
@@ -396,7 +454,7 @@ class BlendingEngine:
         for is dropped at the end of the level."""
         import heapq
         tree = self._tree
-        ready = {}                    # (f_left, f_right) -> dict(fract, traj, frame, sl, sr)
+        ready = dict(ready) if ready else {}     # (f_left, f_right) -> dict(fract, traj, frame, sl, sr)
         remaining = stems
         while remaining > 0:
             # 1) commit everything the greedy order can already consume

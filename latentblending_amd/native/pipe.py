@@ -298,6 +298,101 @@ class StableDiffusionXLPipeline:
         return trajs
 
     @torch.no_grad()
+    def native_run_wavefront(self, anchor_conds: Sequence[tuple], anchor_starts: Sequence[torch.Tensor],
+                             mid_conds: Sequence[tuple], mid_fracts: Sequence[float],
+                             mid_coeffs: Sequence[Sequence[float]], idx_injection: int, num_inference_steps: int,
+                             guidance_anchor: float, guidance_mids: Sequence[float]):
+        """Both anchors AND a set of mid branches whose parents are the anchors, in one wavefront.
+
+        A mid branch at step i only needs the anchors' latents of step i-1 (its start latent and its
+        crossfeed targets are slerps of the anchors' previous-step latents, blending_engine.py:443-464
+        of the reference), so from ``idx_injection`` on the anchors' step i and every mid branch's step
+        i share ONE UNet batch of 2+G samples: 2 small + (steps-idx) large forwards instead of
+        ``steps`` small + (steps-idx) large ones.  Arithmetic per sample is the same as in the
+        separate runs.  Returns (trajectory anchor 1, trajectory anchor 2, [mid trajectories])."""
+        A, G = 2, len(mid_conds)
+        sched, steps = self.scheduler, num_inference_steps
+        if sched.num_inference_steps != steps:
+            sched.set_timesteps(steps)
+        all_g = [float(guidance_anchor)] * A + [float(g) for g in guidance_mids]
+        self._guidance_scale = all_g[-1]
+        cfg = max(all_g) > 1 and self.unet.config.time_cond_proj_dim is None
+        mul = 2 if cfg else 1
+        L = anchor_starts[0].shape[-1]
+        per_sample = anchor_starts[0][0].numel()
+
+        def conditioning(conds):
+            pos_ctx = torch.cat([c[0] for c in conds]).to(self.device, F16)
+            pos_pool = torch.cat([c[2] for c in conds]).to(self.device, F16)
+            if not cfg:
+                return pos_ctx, pos_pool
+            neg_ctx = torch.cat([c[1] for c in conds]).to(self.device, F16)
+            neg_pool = torch.cat([c[3] for c in conds]).to(self.device, F16)
+            return torch.cat([neg_ctx, pos_ctx]), torch.cat([neg_pool, pos_pool])
+
+        def prepared(conds):
+            prog = self.unet_program(len(conds) * mul, L)
+            ctx, pooled = conditioning(conds)
+            ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
+            prog.set_conditioning(ctx, pooled, ids)
+            return prog
+
+        prog_a = prepared(list(anchor_conds)) if idx_injection > 0 else None
+        prog_all = prepared(list(anchor_conds) + list(mid_conds))
+        stream = torch.cuda.current_stream().cuda_stream
+        rows_a = [sched.step_row(i, all_g[0]) for i in range(steps)]
+        par_a = ops.step_params([r for r in rows_a for _ in range(A)], self.device).view(steps, A, 8)
+        par_all = ops.step_params([sched.step_row(i, all_g[s]) for i in range(idx_injection, steps)
+                                   for s in range(A + G)], self.device).view(-1, A + G, 8)
+        shape1 = (1,) + tuple(anchor_starts[0].shape[1:])
+        noise_a = noise_m = None
+        if sched.ancestral:       # sample-major draws: anchor 1, anchor 2, then every mid branch
+            noise_a = torch.stack([torch.cat([sched.draw_noise(shape1, self.device) for _ in range(steps)])
+                                   for _ in range(A)], dim=1)
+            noise_m = torch.stack([torch.cat([sched.draw_noise(shape1, self.device) for _ in range(idx_injection, steps)])
+                                   for _ in range(G)], dim=1) if G else None
+        lat_a = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in anchor_starts]).contiguous()
+        lat_m = None
+        traj_a = [[], []]
+        traj_m: List[List[Optional[torch.Tensor]]] = [[None] * idx_injection for _ in range(G)]
+        fr = [float(f) for f in mid_fracts]
+        for i in range(steps):
+            if i < idx_injection:
+                prog, lat, params, n = prog_a, lat_a, par_a[i], A
+                noise = noise_a[i] if noise_a is not None else None
+            else:
+                prev1, prev2 = traj_a[0][i - 1], traj_a[1][i - 1]
+                mix_prev = ops.slerp_pairs([prev1] * G, [prev2] * G, fr)              # parental mix of step i-1
+                self.stats["slerps"] += G
+                if i == idx_injection:
+                    lat_m = torch.cat(mix_prev)
+                feed = [g for g in range(G) if mid_coeffs[g][i] > 0]
+                if feed:
+                    outs = ops.slerp_pairs([lat_m[g:g + 1] for g in feed], [mix_prev[g] for g in feed],
+                                           [float(mid_coeffs[g][i]) for g in feed])
+                    self.stats["slerps"] += len(feed)
+                    lat_m = lat_m.clone()
+                    for g, o in zip(feed, outs):
+                        lat_m[g:g + 1] = o
+                prog, lat, params, n = prog_all, torch.cat([lat_a, lat_m]), par_all[i - idx_injection], A + G
+                noise = torch.cat([noise_a[i], noise_m[i - idx_injection]]) if noise_a is not None else None
+            api.lb_scale_model_input_f16(lat.data_ptr(), prog.x_in.data_ptr(), params.data_ptr(), per_sample, n,
+                                         int(cfg), stream)
+            prog.tvals.fill_(float(sched.timesteps_np[i]))
+            prog.prog_step.launch(stream)
+            self.stats["unet_forwards"] += 1
+            self.stats["unet_samples"] += prog.B
+            out = ops.euler_step(lat, prog.eps, params, noise=noise, cfg=cfg, ancestral=sched.ancestral)
+            lat_a = out[:A]
+            traj_a[0].append(out[0:1])
+            traj_a[1].append(out[1:2])
+            if i >= idx_injection:
+                lat_m = out[A:]
+                for g in range(G):
+                    traj_m[g].append(out[A + g:A + g + 1])
+        return traj_a[0], traj_a[1], traj_m
+
+    @torch.no_grad()
     def native_latent2image_batch(self, latents: Sequence[torch.Tensor], output_type="pil"):
         z = torch.cat([t.to(self.device, F16).reshape(1, -1, t.shape[-2], t.shape[-1]) for t in latents])
         prog = self.vae_program(z.shape[0], z.shape[-1])
