@@ -93,6 +93,11 @@ typedef struct LbGemmParams {
     int splitk;              /* set by the launcher */
     const void* zero_page;   /* >= 16 zero bytes, 16-B aligned (source of masked chunks for the
                                 direct-to-LDS variant); NULL = register-ring variant only */
+    /* sub-pixel form of "nearest-2x upsample + 3x3 conv": four 2x2 convs on the LOW-res grid, one per
+     * output parity (sc_py, sc_px), with pre-summed weights (4/9 of the FLOPs).  scatter = 1:
+     * KH = KW = 2, Hout = Hin, Wout = Win, pad is implied (1 - parity) and row m = (b, y, x) is
+     * stored at pixel (2y + sc_py, 2x + sc_px) of the [B][2H][2W][ldc] output. */
+    int scatter, sc_py, sc_px, reserved_;
 } LbGemmParams;
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);

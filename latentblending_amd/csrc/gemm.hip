@@ -97,8 +97,8 @@ __global__ void __launch_bounds__(256) gemm_f16_kernel(const LbGemmParams p) {
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
             a_off[i] = a_ok[i] ? (long)b * p.Hin * p.Win * p.ldx : 0;
-            a_iy[i] = oy * p.stride - p.pad;
-            a_ix[i] = ox * p.stride - p.pad;
+            a_iy[i] = oy * p.stride - (p.scatter ? 1 - p.sc_py : p.pad);
+            a_ix[i] = ox * p.stride - (p.scatter ? 1 - p.sc_px : p.pad);
         } else {
             a_off[i] = a_ok[i] ? (long)m * p.lda : 0;
             a_iy[i] = a_ix[i] = 0;
@@ -409,6 +409,10 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(p.Cin % 8 == 0 && p.ldx % 8 == 0, "lb_gemm_f16: conv Cin/ldx must be multiples of 8");
         LB_REQUIRE(p.K == p.KH * p.KW * p.Cin, "lb_gemm_f16: conv K != KH*KW*Cin");
         LB_REQUIRE(p.M % (p.Hout * p.Wout) == 0, "lb_gemm_f16: conv M must be B*Hout*Wout");
+        if (p.scatter)
+            LB_REQUIRE(p.KH == 2 && p.KW == 2 && p.stride == 1 && p.ups == 0 && p.Hout == p.Hin && p.Wout == p.Win &&
+                           !(p.flags & (LB_GEMM_TRANS_OUT | LB_GEMM_GEGLU)) && p.residual == nullptr,
+                       "lb_gemm_f16: sub-pixel conv needs KH=KW=2, stride 1, Hout=Hin, no residual");
     } else {
         LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
     }

@@ -80,8 +80,8 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
             a_off[i] = (long)b * p.Hin * p.Win * p.ldx;
-            a_iy[i] = oy * p.stride - p.pad;
-            a_ix[i] = ox * p.stride - p.pad;
+            a_iy[i] = oy * p.stride - (p.scatter ? 1 - p.sc_py : p.pad);
+            a_ix[i] = ox * p.stride - (p.scatter ? 1 - p.sc_px : p.pad);
         } else {
             a_off[i] = (long)m * p.lda;
             a_iy[i] = a_ix[i] = 0;

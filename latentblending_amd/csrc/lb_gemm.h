@@ -38,14 +38,21 @@ __device__ __forceinline__ void lb_gemm_store4(const LbGemmParams& p, int m, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
     }
+    long crow = m;                      // output row; sub-pixel convs scatter to the 2x-upsampled grid
+    if (p.scatter) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.Wout, x = rem - y * p.Wout;
+        crow = ((long)b * 2 * p.Hout + 2 * y + p.sc_py) * (2 * p.Wout) + 2 * x + p.sc_px;
+    }
     if (p.flags & LB_GEMM_TRANS_OUT) {
         f16* c = (f16*)p.C;
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[(long)(n + r) * p.ldc + m] = (f16)o[r];
     } else if (p.flags & LB_GEMM_OUT_F32) {
-        *reinterpret_cast<f32x4*>((float*)p.C + (long)m * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>((float*)p.C + crow * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
     } else {
-        *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) =
+        *reinterpret_cast<f16x4*>((f16*)p.C + crow * p.ldc + n) =
             (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
     }
 }

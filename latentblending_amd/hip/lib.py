@@ -30,6 +30,7 @@ class LbGemmParams(C.Structure):
         ("Hout", C.c_int), ("Wout", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
+        ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
     ]
 
 

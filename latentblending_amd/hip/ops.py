@@ -118,6 +118,27 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Te
     return out.reshape(cout, kh * kw * cp)
 
 
+def subpixel_upsample_weights(w: torch.Tensor, cin_pad: Optional[int] = None):
+    """3x3 conv weight [Cout, Cin, 3, 3] applied after a nearest-2x upsample  ->  four packed 2x2 kernels
+    {(py, px): fp16 [Cout, 2*2*Cin_pad]} acting on the low-res grid: output pixel (2y+py, 2x+px) sees only
+    a 2x2 low-res neighbourhood, the taps that fall on the same source pixel are summed (in fp32)."""
+    cout, cin, _, _ = w.shape
+    cp = cin_pad or (cin + 7) // 8 * 8
+    w = w.float()
+    rows = {0: [w[:, :, 0], w[:, :, 1] + w[:, :, 2]], 1: [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]}   # [Cout,Cin,3(kx)]
+    out = {}
+    for py in (0, 1):
+        for px in (0, 1):
+            k = torch.zeros(cout, 2, 2, cp, dtype=torch.float32, device=w.device)
+            for a in (0, 1):
+                r = rows[py][a]                                            # [Cout, Cin, 3]
+                cols = [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if px == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
+                for b in (0, 1):
+                    k[:, a, b, :cin] = cols[b]
+            out[(py, px)] = k.reshape(cout, 4 * cp).to(F16).contiguous()
+    return out
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          flags: int = 0, alpha: float = 1.0, out: Optional[torch.Tensor] = None, splitk_ws: bool = True,
          conv: Optional[dict] = None, M: Optional[int] = None) -> torch.Tensor:
@@ -136,6 +157,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
         p.conv, p.Hin, p.Win, p.Cin, p.Hout, p.Wout = 1, H, Wd, Cin, hout, wout
         p.KH, p.KW, p.stride, p.pad, p.ups, p.ldx = kh, kw, st, pad, ups, A.stride(2)
         out_shape = (B, hout, wout)
+        if "parity" in conv:                          # sub-pixel upsampling conv: caller supplies `out`
+            p.scatter, p.sc_py, p.sc_px = 1, int(conv["parity"][0]), int(conv["parity"][1])
+            hout, wout = H, Wd
+            Mv = B * H * Wd
+            p.Hout, p.Wout = H, Wd
     else:
         Mv = M if M is not None else A.shape[0]
         p.lda = A.stride(0)

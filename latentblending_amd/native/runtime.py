@@ -175,6 +175,8 @@ class Emitter:
             p.conv = 1
             for k in ("Hin", "Win", "Cin", "Hout", "Wout", "KH", "KW", "stride", "pad", "ups", "ldx"):
                 setattr(p, k, int(conv[k]))
+            if "parity" in conv:                       # sub-pixel upsampling conv
+                p.scatter, p.sc_py, p.sc_px = 1, int(conv["parity"][0]), int(conv["parity"][1])
         else:
             p.lda = lda if lda is not None else K
         p.ldc = ldc if ldc is not None else (M if flags & lib.GEMM_TRANS_OUT else n_out)

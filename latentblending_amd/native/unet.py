@@ -91,6 +91,14 @@ class NativeUNet:
         b[:cout] = pv.bias(name + ".bias", cout)
         self.w[name + ".bias"] = self._dev(b, F32)
 
+    def _upconv(self, pv, name, c):
+        """Upsampler conv (nearest-2x, then 3x3) stored as four 2x2 sub-pixel kernels (4/9 of the FLOPs)."""
+        from ..hip.ops import subpixel_upsample_weights
+        w = pv.weight(name + ".weight", (c, c, 3, 3), c * 9, 1.0)
+        for (py, px), k in subpixel_upsample_weights(w, _pad(c, 8)).items():
+            self.w[f"{name}.weight.sub{py}{px}"] = k.to(self.device)
+        self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
+
     def _norm(self, pv, name, c):
         self.w[name + ".weight"] = self._dev(pv.norm_weight(name + ".weight", c), F32)
         self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
@@ -189,7 +197,7 @@ class NativeUNet:
                 if depths[ui]:
                     self._transformer(pv, f"up_blocks.{ui}.attentions.{li}", c, depths[ui], ctx_acc)
             if ui < len(ch) - 1:
-                self._conv(pv, f"up_blocks.{ui}.upsamplers.0.conv", c, c, 3)
+                self._upconv(pv, f"up_blocks.{ui}.upsamplers.0.conv", c)
         self._norm(pv, "conv_norm_out", ch[0])
         self._conv(pv, "conv_out", ch[0], cfg.out_channels, 3, gain=0.5)
         # fused projections
@@ -251,6 +259,17 @@ class UNetProgram:
                 conv=dict(Hin=H, Win=W, Cin=cin_p, Hout=ho, Wout=wo, KH=k, KW=k, stride=stride, pad=pad,
                           ups=ups, ldx=cin_p))
         return out, ho, wo
+
+    def _upconv(self, x, name, B, H, W, c):
+        """nearest-2x upsample + 3x3 conv as four sub-pixel 2x2 convs scattered into the 2H x 2W output."""
+        em, w = self.em, self.net.w
+        out = self.arena.alloc((B, 2 * H, 2 * W, c))
+        for py in (0, 1):
+            for px in (0, 1):
+                em.gemm(x, w[f"{name}.weight.sub{py}{px}"], out, M=B * H * W, bias=w[name + ".bias"], ldc=c,
+                        conv=dict(Hin=H, Win=W, Cin=c, Hout=H, Wout=W, KH=2, KW=2, stride=1, pad=0, ups=0, ldx=c,
+                                  parity=(py, px)))
+        return out, 2 * H, 2 * W
 
     def _resnet(self, x, p, B, H, W, cin, cout):
         em, w, ar, g = self.em, self.net.w, self.arena, self.net.cfg.norm_groups
@@ -417,7 +436,7 @@ class UNetProgram:
                     ar.release(h)
                     h = nxt
             if ui < len(ch) - 1:
-                nxt, side, _ = self._conv(h, f"up_blocks.{ui}.upsamplers.0.conv", B, side, side, c, c, ups=1)
+                nxt, side, _ = self._upconv(h, f"up_blocks.{ui}.upsamplers.0.conv", B, side, side, c)
                 ar.release(h)
                 h = nxt
         n = ar.alloc((B, side, side, ch[0]))

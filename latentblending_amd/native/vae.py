@@ -63,6 +63,13 @@ class NativeVAEDecoder:
         b[:cout] = pv.bias(name + ".bias", cout)
         self.w[name + ".bias"] = self._dev(b, F32)
 
+    def _upconv(self, pv, name, c):
+        from ..hip.ops import subpixel_upsample_weights
+        w = pv.weight(name + ".weight", (c, c, 3, 3), c * 9, 1.0)
+        for (py, px), k in subpixel_upsample_weights(w, _pad(c, 8)).items():
+            self.w[f"{name}.weight.sub{py}{px}"] = k.to(self.device)
+        self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
+
     def _norm(self, pv, name, c):
         self.w[name + ".weight"] = self._dev(pv.norm_weight(name + ".weight", c), F32)
         self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
@@ -103,7 +110,7 @@ class NativeVAEDecoder:
                 self._resnet(pv, f"decoder.up_blocks.{ui}.resnets.{li}", prev, c)
                 prev = c
             if ui < len(rev) - 1:
-                self._conv(pv, f"decoder.up_blocks.{ui}.upsamplers.0.conv", c, c, 3)
+                self._upconv(pv, f"decoder.up_blocks.{ui}.upsamplers.0.conv", c)
         self._norm(pv, "decoder.conv_norm_out", rev[-1])
         self._conv(pv, "decoder.conv_out", rev[-1], cfg.out_channels, 3, gain=0.5)
 
@@ -217,8 +224,14 @@ class VAEProgram:
                 h16 = ar.alloc((B, side, side, c))
                 api.lb_cast_f32_to_f16(h.data_ptr(), h16.data_ptr(), h.numel(), STREAM_SCALE, _stream())
                 ar.release(h)
-                h = self._conv(h16, f"decoder.up_blocks.{ui}.upsamplers.0.conv", B, side, side, c, c, ups=1,
-                               alpha=1.0 / STREAM_SCALE)
+                name = f"decoder.up_blocks.{ui}.upsamplers.0.conv"
+                h = ar.alloc((B, 2 * side, 2 * side, c), F32)
+                for py in (0, 1):           # sub-pixel form of upsample+conv: four 2x2 convs on the low-res grid
+                    for px in (0, 1):
+                        em.gemm(h16, w[f"{name}.weight.sub{py}{px}"], h, M=B * side * side, bias=w[name + ".bias"],
+                                ldc=c, flags=lib.GEMM_OUT_F32, alpha=1.0 / STREAM_SCALE,
+                                conv=dict(Hin=side, Win=side, Cin=c, Hout=side, Wout=side, KH=2, KW=2, stride=1, pad=0,
+                                          ups=0, ldx=c, parity=(py, px)))
                 ar.release(h16)
                 side *= 2
         n = ar.alloc((B, side, side, rev[-1]))

@@ -474,3 +474,23 @@ def test_gemm_glds_variant(tile, stages, results_log):
     finally:
         l.api.lb_gemm_set_variant(0, 0)
         l.api.lb_gemm_set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_subpixel_upsample_conv(variant, results_log):
+    """upsample(nearest 2x) + conv3x3 computed as four 2x2 sub-pixel convs scattered into the output."""
+    o, l = ops(), lib()
+    import ctypes as C
+    B, H, Wd, Cc = 2, 16, 12, 64
+    x, w = rnd(B, Cc, H, Wd, seed=90), rnd(Cc, Cc, 3, 3, seed=91, scale=(9 * Cc) ** -0.5)
+    bias = rnd(Cc, seed=92, dtype=torch.float32)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.zeros(B, 2 * H, 2 * Wd, Cc, dtype=torch.float16, device=DEV)
+    l.api.lb_gemm_set_variant(variant, 0)
+    try:
+        for (py, px), k in o.subpixel_upsample_weights(w).items():
+            o.gemm(xn, k.to(DEV), bias=bias.to(DEV), out=out, conv=dict(KH=2, KW=2, stride=1, pad=0, parity=(py, px)))
+    finally:
+        l.api.lb_gemm_set_variant(1, 0)
+    check_close(results_log, f"subpixel_upconv_v{variant}", out, ref, rel=3e-3)
