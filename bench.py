@@ -97,6 +97,17 @@ def gemm_family_profile(pipe, launches):
     return tot
 
 
+def _pmc_traffic_per_launch():
+    """HBM traffic of the GEMM family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE),
+    per launch like `achieved`; PMC collection cannot run inside the timed bench itself."""
+    path = os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["gemm_family_hbm_traffic"]["bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(unet_w, vae_w):
     """Bounded CPU sample on this host: one fp32 UNet forward + one fp32 VAE decode of the oracle
     at the benchmark shapes (B=1, 64x64 latent), scaled by the transition census (38 / 17)."""
@@ -228,7 +239,10 @@ def _run():
         out["roofline"] = {
             "bound": "mfma", "kernel": "gemm_f16_kernel<BM,BN,CONV,GEGLU> (all Linear/Conv of UNet+VAE)",
             "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": _pmc_traffic_per_launch(),
+            "traffic_unit": "HBM-side bytes per GEMM launch (rocprofv3 PMC passes committed in profiles/; null if absent)",
+            "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
+            "algorithmic_tflop_per_transition_reference": 103.1,
             "per_transition": {"gemm_tflop": prof["gemm_flops"] / 1e12, "gemm_ms": prof["gemm_ms"],
                                "gemm_launches": prof["gemm_launches"],
                                "gemm_avg_us_per_launch": prof["gemm_ms"] * 1e3 / max(prof["gemm_launches"], 1),
