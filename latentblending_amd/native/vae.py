@@ -3,13 +3,17 @@ reached from /root/reference/latentblending/diffusers_holder.py:115-143) for gfx
 
 Precision plan (replaces the reference's "upcast the whole VAE to fp32 on every decode",
 diffusers_holder.py:129-139): the SDXL VAE overflows fp16 in its residual stream, not in its
-normalised activations.  So
-  * the residual stream and every conv output are kept in **fp32** (GEMM epilogue ``OUT_F32``),
-  * GroupNorm(+SiLU) reads fp32 and writes **fp16** (bounded after normalisation) — these are the
-    MFMA operands, accumulated in fp32,
-  * the two places where the raw stream itself feeds a contraction (1x1 shortcuts, upsampler
-    convs) down-scale by 2^-4 while casting to fp16 and multiply back in the epilogue (``alpha``).
-Net effect: fp16 MFMA rate (16x the fp32 rate on gfx950) with fp32 range where it matters.
+normalised activations.  GroupNorm(+SiLU) outputs are bounded, so they are the fp16 MFMA operands
+(fp32 accumulate); the residual stream itself (and conv outputs that only feed the next GroupNorm)
+is kept in one of two formats:
+  * ``stream_fp16_scaled`` (default): fp16 holding value * 2^-4 — range +-1e6, ~5e-4 relative
+    precision, half the HBM traffic of fp32 for the bandwidth-bound GroupNorm passes and conv
+    epilogues.  The scale rides along for free: conv epilogues use alpha = 2^-4 and biases
+    pre-multiplied by 2^-4 (exact), GroupNorm is scale invariant once eps is scaled by 2^-8, and the
+    1x1 shortcut / upsampler convs consume the scaled stream directly (linear ops);
+  * fp32 stream (``stream_fp16_scaled=False``): ``OUT_F32`` epilogues, GroupNorm reads fp32, the
+    two raw-stream contractions cast with the same 2^-4 scale and multiply back in the epilogue.
+Either way the MFMA work runs at the fp16 rate (16x the fp32 MFMA rate on gfx950).
 The mid-block attention (1 head, d = 512) is GEMM -> row softmax -> GEMM; its V bias is folded
 into the output projection bias at load time (softmax rows sum to 1).
 Output is quantised on device to uint8 NHWC frames.
@@ -38,6 +42,7 @@ class VAEConfig:
     norm_groups: int = 32
     scaling_factor: float = 0.13025
     force_upcast: bool = True
+    stream_fp16_scaled: bool = True      # residual stream as fp16 * 2^-4 (False: fp32 stream)
 
     @property
     def scale_factor(self) -> int:
@@ -113,6 +118,8 @@ class NativeVAEDecoder:
                 self._upconv(pv, f"decoder.up_blocks.{ui}.upsamplers.0.conv", c)
         self._norm(pv, "decoder.conv_norm_out", rev[-1])
         self._conv(pv, "decoder.conv_out", rev[-1], cfg.out_channels, 3, gain=0.5)
+        for key in [k for k in self.w if k.endswith(".bias")]:          # biases in stream units (x 2^-4, exact)
+            self.w[key + "_s"] = self.w[key] * STREAM_SCALE
 
     def build(self, B: int, L: int) -> "VAEProgram":
         return VAEProgram(self, B, L)
@@ -122,6 +129,7 @@ class VAEProgram:
     def __init__(self, net: NativeVAEDecoder, B: int, L: int):
         cfg = net.cfg
         self.net, self.B, self.L = net, B, L
+        self.scaled = bool(cfg.stream_fp16_scaled)
         dev = net.device
         self.arena = Arena(dev)
         self.em = Emitter(self.arena)
@@ -134,52 +142,67 @@ class VAEProgram:
         with self.prog.record():
             self._emit()
 
-    def _conv(self, x, name, B, H, W, cin, cout, *, ups=0, residual=None, alpha=1.0, out=None):
-        w = self.net.w
-        he, we = H << ups, W << ups
+    # ---- residual-stream format --------------------------------------------------------------
+    # scaled (default): stream tensors hold value * 2^-4 in fp16;  f32: plain fp32 (see module docstring)
+    def _stream_conv(self, x, name, B, H, W, cin, cout, *, residual=None, out=None):
+        """3x3 conv whose output goes to the residual stream (or feeds only the next GroupNorm)."""
+        w, sc = self.net.w, self.scaled
         cin_p, cout_p = _pad(cin, 8), _pad(cout, 4)
         if out is None:
-            out = self.arena.alloc((B, he, we, cout_p), F32)
-        flags = lib.GEMM_OUT_F32 | (lib.GEMM_RES_F32 if residual is not None else 0)
-        self.em.gemm(x, w[name + ".weight"], out, M=B * he * we, bias=w[name + ".bias"], residual=residual,
-                     flags=flags, alpha=alpha,
-                     conv=dict(Hin=H, Win=W, Cin=cin_p, Hout=he, Wout=we, KH=3, KW=3, stride=1, pad=1, ups=ups,
-                               ldx=cin_p))
+            out = self.arena.alloc((B, H, W, cout_p), F16 if sc else F32)
+        flags = 0 if sc else (lib.GEMM_OUT_F32 | (lib.GEMM_RES_F32 if residual is not None else 0))
+        self.em.gemm(x, w[name + ".weight"], out, M=B * H * W, bias=w[name + (".bias_s" if sc else ".bias")],
+                     residual=residual, flags=flags, alpha=STREAM_SCALE if sc else 1.0,
+                     conv=dict(Hin=H, Win=W, Cin=cin_p, Hout=H, Wout=W, KH=3, KW=3, stride=1, pad=1, ups=0, ldx=cin_p))
         return out
 
+    def _gn(self, x, out, name, B, HW, c, silu):
+        w = self.net.w
+        eps = 1e-6 * (STREAM_SCALE * STREAM_SCALE if self.scaled else 1.0)     # GroupNorm of a scaled tensor
+        self.em.groupnorm(x, out, w[name + ".weight"], w[name + ".bias"], B=B, HW=HW, C_=c, eps=eps, silu=silu,
+                          groups=self.net.cfg.norm_groups)
+
+    def _stream_as_operand(self, x, B, H, W, c):
+        """The raw stream as an fp16 MFMA operand carrying the 2^-4 scale: free in scaled mode, a
+        saturating down-scaling cast in fp32 mode.  Returns (tensor, owned)."""
+        if self.scaled:
+            return x, False
+        x16 = self.arena.alloc((B, H, W, c))
+        api.lb_cast_f32_to_f16(x.data_ptr(), x16.data_ptr(), x.numel(), STREAM_SCALE, _stream())
+        return x16, True
+
     def _resnet(self, x, p, B, H, W, cin, cout):
-        em, w, ar, g = self.em, self.net.w, self.arena, self.net.cfg.norm_groups
+        em, w, ar, sc = self.em, self.net.w, self.arena, self.scaled
         n1 = ar.alloc((B, H, W, cin))
-        em.groupnorm(x, n1, w[p + ".norm1.weight"], w[p + ".norm1.bias"], B=B, HW=H * W, C_=cin, eps=1e-6,
-                     silu=True, groups=g)
-        h = self._conv(n1, p + ".conv1", B, H, W, cin, cout)
+        self._gn(x, n1, p + ".norm1", B, H * W, cin, True)
+        h = self._stream_conv(n1, p + ".conv1", B, H, W, cin, cout)
         ar.release(n1)
         n2 = ar.alloc((B, H, W, cout))
-        em.groupnorm(h, n2, w[p + ".norm2.weight"], w[p + ".norm2.bias"], B=B, HW=H * W, C_=cout, eps=1e-6,
-                     silu=True, groups=g)
+        self._gn(h, n2, p + ".norm2", B, H * W, cout, True)
         ar.release(h)
         if cin != cout:
-            x16 = ar.alloc((B, H, W, cin))
-            api.lb_cast_f32_to_f16(x.data_ptr(), x16.data_ptr(), x.numel(), STREAM_SCALE, _stream())
-            xs = ar.alloc((B, H, W, cout), F32)
-            em.gemm(x16, w[p + ".conv_shortcut.weight"], xs, M=B * H * W, bias=w[p + ".conv_shortcut.bias"],
-                    flags=lib.GEMM_OUT_F32, alpha=1.0 / STREAM_SCALE)
-            ar.release(x16)
+            x16, owned = self._stream_as_operand(x, B, H, W, cin)
+            xs = ar.alloc((B, H, W, cout), F16 if sc else F32)
+            # operand carries the 2^-4 scale: scaled mode keeps it (bias pre-scaled), fp32 mode multiplies back
+            em.gemm(x16, w[p + ".conv_shortcut.weight"], xs, M=B * H * W,
+                    bias=w[p + (".conv_shortcut.bias_s" if sc else ".conv_shortcut.bias")],
+                    flags=0 if sc else lib.GEMM_OUT_F32, alpha=1.0 if sc else 1.0 / STREAM_SCALE)
+            if owned:
+                ar.release(x16)
         else:
             xs = x
-        out = self._conv(n2, p + ".conv2", B, H, W, cout, cout, residual=xs)
+        out = self._stream_conv(n2, p + ".conv2", B, H, W, cout, cout, residual=xs)
         ar.release(n2)
         if xs is not x:
             ar.release(xs)
         return out
 
     def _mid_attention(self, h, B, H, W, c):
-        em, w, ar = self.em, self.net.w, self.arena
+        em, w, ar, sc = self.em, self.net.w, self.arena, self.scaled
         a = "decoder.mid_block.attentions.0"
         S = H * W
         n = ar.alloc((B * S, c))
-        em.groupnorm(h, n, w[a + ".group_norm.weight"], w[a + ".group_norm.bias"], B=B, HW=S, C_=c, eps=1e-6,
-                     silu=False, groups=self.net.cfg.norm_groups)
+        self._gn(h, n, a + ".group_norm", B, S, c, False)
         q, k = ar.alloc((B * S, c)), ar.alloc((B * S, c))
         em.gemm(n, w[a + ".to_q.weight"], q, M=B * S, bias=w[a + ".to_q.bias"])
         em.gemm(n, w[a + ".to_k.weight"], k, M=B * S, bias=w[a + ".to_k.bias"])
@@ -194,13 +217,14 @@ class VAEProgram:
             api.lb_softmax_rows_f16(scores.data_ptr(), S, S, S, 1.0, _stream())
             em.gemm(scores, vt[:, b * S:(b + 1) * S], ob, M=S, lda=S)    # W = V^T slice [c, S], ldw = B*S
         ar.release(scores); ar.release(q); ar.release(k); ar.release(vt)
-        em.gemm(o, w[a + ".to_out.0.weight"], h, M=B * S, bias=w[a + ".to_out.0.bias"], residual=h,
-                flags=lib.GEMM_OUT_F32 | lib.GEMM_RES_F32)
+        em.gemm(o, w[a + ".to_out.0.weight"], h, M=B * S, bias=w[a + (".to_out.0.bias_s" if sc else ".to_out.0.bias")],
+                residual=h, flags=0 if sc else (lib.GEMM_OUT_F32 | lib.GEMM_RES_F32), alpha=STREAM_SCALE if sc else 1.0)
         ar.release(o)
         return h
 
     def _emit(self):
         net, cfg, em, w, ar, B, L = self.net, self.net.cfg, self.em, self.net.w, self.arena, self.B, self.L
+        sc = self.scaled
         rev = list(reversed(cfg.block_channels))
         top, lc = rev[0], cfg.latent_channels
         lc_p = _pad(lc, 8)
@@ -210,7 +234,7 @@ class VAEProgram:
         # post_quant_conv (1x1) writes the first `lc` channels of a zero-padded buffer
         em.gemm(z8, w["post_quant_conv.weight"], self._pq, M=B * L * L, bias=w["post_quant_conv.bias"], ldc=lc_p)
         ar.release(z8)
-        h = self._conv(self._pq, "decoder.conv_in", B, L, L, lc, top)
+        h = self._stream_conv(self._pq, "decoder.conv_in", B, L, L, lc, top)
         nxt = self._resnet(h, "decoder.mid_block.resnets.0", B, L, L, top, top); ar.release(h); h = nxt
         h = self._mid_attention(h, B, L, L, top)
         nxt = self._resnet(h, "decoder.mid_block.resnets.1", B, L, L, top, top); ar.release(h); h = nxt
@@ -221,24 +245,28 @@ class VAEProgram:
                 ar.release(h); h = nxt
                 prev = c
             if ui < len(rev) - 1:
-                h16 = ar.alloc((B, side, side, c))
-                api.lb_cast_f32_to_f16(h.data_ptr(), h16.data_ptr(), h.numel(), STREAM_SCALE, _stream())
-                ar.release(h)
+                h16, owned = self._stream_as_operand(h, B, side, side, c)
                 name = f"decoder.up_blocks.{ui}.upsamplers.0.conv"
-                h = ar.alloc((B, 2 * side, 2 * side, c), F32)
+                up = ar.alloc((B, 2 * side, 2 * side, c), F16 if sc else F32)
                 for py in (0, 1):           # sub-pixel form of upsample+conv: four 2x2 convs on the low-res grid
                     for px in (0, 1):
-                        em.gemm(h16, w[f"{name}.weight.sub{py}{px}"], h, M=B * side * side, bias=w[name + ".bias"],
-                                ldc=c, flags=lib.GEMM_OUT_F32, alpha=1.0 / STREAM_SCALE,
+                        em.gemm(h16, w[f"{name}.weight.sub{py}{px}"], up, M=B * side * side,
+                                bias=w[name + (".bias_s" if sc else ".bias")], ldc=c,
+                                flags=0 if sc else lib.GEMM_OUT_F32, alpha=1.0 if sc else 1.0 / STREAM_SCALE,
                                 conv=dict(Hin=side, Win=side, Cin=c, Hout=side, Wout=side, KH=2, KW=2, stride=1, pad=0,
                                           ups=0, ldx=c, parity=(py, px)))
-                ar.release(h16)
+                if owned:
+                    ar.release(h16)
+                ar.release(h)
+                h = up
                 side *= 2
         n = ar.alloc((B, side, side, rev[-1]))
-        em.groupnorm(h, n, w["decoder.conv_norm_out.weight"], w["decoder.conv_norm_out.bias"], B=B, HW=side * side,
-                     C_=rev[-1], eps=1e-6, silu=True, groups=cfg.norm_groups)
+        self._gn(h, n, "decoder.conv_norm_out", B, side * side, rev[-1], True)
         ar.release(h)
-        self._conv(n, "decoder.conv_out", B, side, side, rev[-1], cfg.out_channels, out=self.image_f32)
+        cin_p = _pad(rev[-1], 8)
+        em.gemm(n, w["decoder.conv_out.weight"], self.image_f32, M=B * side * side, bias=w["decoder.conv_out.bias"],
+                flags=lib.GEMM_OUT_F32,
+                conv=dict(Hin=side, Win=side, Cin=cin_p, Hout=side, Wout=side, KH=3, KW=3, stride=1, pad=1, ups=0, ldx=cin_p))
         ar.release(n)
         api.lb_postprocess_u8(self.image_f32.data_ptr(), self.frames.data_ptr(), B * side * side,
                               _pad(cfg.out_channels, 4), 1, _stream())

@@ -72,11 +72,13 @@ def test_unet_tiny_matches_oracle(B, L, results_log):
     assert rel_l2(graph2, ref2) <= 1e-2
 
 
-def test_vae_tiny_matches_oracle(results_log):
+@pytest.mark.parametrize("scaled_stream", [True, False])
+def test_vae_tiny_matches_oracle(scaled_stream, results_log):
     n = native()
     cfg = R.tiny_vae_cfg()
     w = R.make_weights(R.vae_decoder_spec(cfg), 1)
-    net = n.NativeVAEDecoder(n.VAEConfig(**dataclasses.asdict(cfg)), n.SyntheticProvider(1), DEV)
+    net = n.NativeVAEDecoder(n.VAEConfig(**dataclasses.asdict(cfg), stream_fp16_scaled=scaled_stream),
+                             n.SyntheticProvider(1), DEV)
     z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5)).half()
     ref_img = R.vae_decode(cfg, w, z.float() / cfg.scaling_factor)
     ref_u8 = R.postprocess_u8(ref_img)
@@ -84,7 +86,7 @@ def test_vae_tiny_matches_oracle(results_log):
     got_u8 = prog.decode(z.to(DEV)).cpu().numpy()
     r = rel_l2(prog.image_f32[..., :3].permute(0, 3, 1, 2), ref_img)
     d = np.abs(got_u8.astype(np.int32) - ref_u8.astype(np.int32))
-    results_log["vae_tiny"] = {"rel_l2": r, "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean())}
+    results_log[f"vae_tiny_scaled{int(scaled_stream)}"] = {"rel_l2": r, "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean())}
     print(f"[parity] vae tiny: rel_l2={r:.3e} mean|du8|={d.mean():.3f} within4={(d <= 4).mean():.4f}")
     assert r <= 1e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99
     prog.prog.instantiate()
