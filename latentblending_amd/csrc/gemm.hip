@@ -426,7 +426,12 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         return (long)((p.M + bm - 1) / bm) * ((n_eff + bn_eff - 1) / bn_eff);
     };
     int tile = g_force_tile;
-    if (!tile) tile = blocks(128, 128) >= 224 ? 1 : 3;   // 128x64 never won the sweep (tools/sweep_gemm.py)
+    if (!tile) {
+        // MI355X sweep (tools/sweep_gemm.py, profiles/r01_gemm_variant_sweep.txt): big grids -> 128x128,
+        // one-to-three waves of 128x128 tiles -> 128x64 (more blocks, same A panel), small grids -> 64x64
+        const long b128 = blocks(128, 128);
+        tile = b128 >= 700 ? 1 : (b128 >= 224 ? (g_variant == 1 ? 2 : 1) : 3);
+    }
     const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
     const long nblk = blocks(bm, bn);
     int splitk = 1;
@@ -449,7 +454,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     int stages = g_stages;
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
-        if (stages == 0) stages = tile == 1 ? 2 : 3;   // 128x128: 2 x 32 KiB (2 blocks/CU); 64x64: 3 x 16 KiB
+        if (stages == 0) stages = tile == 3 ? 3 : 2;   // 128x128 / 128x64: 2 stages (2-3 blocks/CU); 64x64: 3 x 16 KiB
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));
