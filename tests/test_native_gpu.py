@@ -325,3 +325,60 @@ def test_branch_farm_on_rccl_world1(results_log):
         results_log["farm_rccl_world1"] = {"collectives": farm.collectives, "bytes": farm.bytes_moved}
     finally:
         dist.destroy_process_group()
+
+
+def _farm_native_worker(rank, world, port, out_dir):
+    import json as _json
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import latentblending_amd.native as N
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.dist import BranchFarm
+    ucfg, vcfg = R.tiny_unet_cfg(), R.tiny_vae_cfg()
+    pipe = N.NativeSDXLPipe(turbo=True, unet_cfg=N.UNetConfig(**dataclasses.asdict(ucfg)),
+                            vae_cfg=N.VAEConfig(**dataclasses.asdict(vcfg)), seed=0, device="cuda:0")
+    tape = OP.NoiseTape(12345)
+    pipe.scheduler.noise_source = tape
+    np.random.seed(0)
+    farm = BranchFarm(device=torch.device("cpu")) if world > 1 else None      # both ranks share cuda:0 -> gloo
+    be = BlendingEngine(pipe, verbose=False, frontier_width=4 * world, farm=farm, do_compile=True)
+    be.set_dimensions((128, 128))
+    be.set_branching(nmb_max_branches=9)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+    tape.reset()
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    res = {"fracts": [float(f) for f in be.tree_fracts], "sims": [float(s) for s in be.tree_similarities],
+           "frames": [int(np.asarray(i).astype(np.int64).sum()) for i in imgs], "samples": pipe.stats["unet_samples"],
+           "collectives": 0 if farm is None else farm.collectives}
+    _json.dump(res, open(os.path.join(out_dir, f"native_rank{rank}_of{world}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_with_native_pipes_two_ranks(tmp_path, results_log):
+    """Two SPMD ranks with NATIVE pipes (sharing the single GPU, gloo for the collectives): same tree
+    and frames on both ranks and as the one-rank run; the UNet work is split between the ranks."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+
+    def port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+    mp.spawn(_farm_native_worker, args=(1, port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_farm_native_worker, args=(2, port(), str(tmp_path)), nprocs=2, join=True)
+    solo = json.load(open(tmp_path / "native_rank0_of1.json"))
+    r0, r1 = [json.load(open(tmp_path / f"native_rank{r}_of2.json")) for r in (0, 1)]
+    assert r0["fracts"] == r1["fracts"] == solo["fracts"]
+    assert r0["sims"] == r1["sims"] and r0["frames"] == r1["frames"]
+    assert np.allclose(r0["sims"], solo["sims"], rtol=2e-2)
+    assert r0["collectives"] > 0
+    assert r0["samples"] < solo["samples"] and r1["samples"] < solo["samples"]
+    results_log["farm_native_2ranks"] = {"samples": [r0["samples"], r1["samples"], solo["samples"]],
+                                         "collectives": r0["collectives"]}
