@@ -507,7 +507,7 @@ class BlendingEngine:
                 results = self.farm.exchange_branches([(t, f, 0.0, 0.0) for t, f in mine], len(specs),
                                                       self.num_inference_steps - idx_injection,
                                                       self.num_inference_steps, make_frame=self._frame_from_u8)
-                results = [(t, f) for t, f, _, _ in results]
+                results = [(self._on_pipe_device(t), f) for t, f, _, _ in results]
             else:
                 results = self._evaluate_specs(specs, idx_injection)
             frame_at = {f: tree.frames[i] for i, f in enumerate(tree.fracts)}
@@ -552,6 +552,14 @@ class BlendingEngine:
             out.append((traj, self.dh.latent2image(traj[-1])))
         return out
 
+    def _on_pipe_device(self, traj):
+        """Exchanged latents live wherever the farm's collectives ran (host for gloo); a native pipe
+        wants them in HBM."""
+        if not _is_native(self.dh.pipe):
+            return traj
+        dev = self.dh.pipe.device
+        return [None if t is None else t.to(dev) for t in traj]
+
     def _frame_from_u8(self, u8: torch.Tensor):
         """uint8 [H,W,3] tensor (as exchanged between ranks) -> the pipe's frame type."""
         if _is_native(self.dh.pipe):
@@ -574,8 +582,8 @@ class BlendingEngine:
             if not independent:
                 self.tree_latents[0] = first
             last = self.compute_latents2()
-        first = farm.share_trajectory(first, 0, steps)
-        last = farm.share_trajectory(last, owner2, steps)
+        first = self._on_pipe_device(farm.share_trajectory(first, 0, steps))
+        last = self._on_pipe_device(farm.share_trajectory(last, owner2, steps))
         self.tree_latents[0], self.tree_latents[-1] = first, last
         return first, last
 
