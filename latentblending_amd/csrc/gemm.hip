@@ -338,7 +338,7 @@ static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     }
 }
 
-static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64
+static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64 4=256x128 (direct-to-LDS only)
 static int g_force_splitk = 0;    // 0 auto
 static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
@@ -348,9 +348,9 @@ extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream);
 void lb_gemm_glds_init();
 static int g_variant = 1, g_stages = 0;   // default: direct-to-LDS staging (wins the MI355X sweep by 5-20 %)
-extern "C" void lb_gemm_set_variant(int variant, int stages) {
-    g_variant = variant;
-    g_stages = stages;
+extern "C" void lb_gemm_set_variant(int variant, int stages) {   // variant < 0: back to the default
+    g_variant = variant < 0 ? 1 : variant;
+    g_stages = variant < 0 ? 0 : stages;
     if (variant == 1) lb_gemm_glds_init();
 }
 
@@ -427,12 +427,25 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     };
     int tile = g_force_tile;
     if (!tile) {
-        // MI355X sweep (tools/sweep_gemm.py, profiles/r01_gemm_variant_sweep.txt): big grids -> 128x128,
-        // one-to-three waves of 128x128 tiles -> 128x64 (more blocks, same A panel), small grids -> 64x64
+        // MI355X sweeps (tools/sweep_gemm.py; profiles/r01_gemm_variant_sweep.txt, r01_gemm_tile4_sweep.txt).
+        // Direct-to-LDS family: the 8-wave 256x128 tile with a 3-stage ring (144 KiB, two K-tiles = 96 KiB
+        // in flight per CU, 25 % less operand traffic per FLOP) wins whenever it fills ~2/3 of the chip,
+        // N does not pad badly to 128 columns and K is long enough to amortise its prologue.  Otherwise
+        // (Convolutions only with >= 4 rounds of such tiles: the UNet's convs measured better on the 4-wave
+        // tiles.)  >= 3 rounds of 128x128 tiles -> 128x128, about one round -> 128x64, small grids -> 64x64.
         const long b128 = blocks(128, 128);
         tile = b128 >= 700 ? 1 : (b128 >= 224 ? (g_variant == 1 ? 2 : 1) : 3);
+        if (n_eff <= 64) tile = 3;                                              // (VAE conv_out: 3 real columns)
+        if (g_variant == 1 && p.zero_page != nullptr) {
+            const long b256 = blocks(256, 128);
+            const int unit = geglu ? 64 : 128;
+            const int n_pad = (n_eff + unit - 1) / unit * unit;
+            const bool n_fits = (long)n_pad * 10 <= (long)n_eff * 11;           // <= 10 % padded columns
+            if (n_fits && (b256 >= 1024 || (!p.conv && b256 >= 160 && p.K >= 1024))) tile = 4;
+        }
     }
-    const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
+    if (tile == 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 256x128: direct-to-LDS family only
+    const int bm = tile == 4 ? 256 : (tile == 3 ? 64 : 128), bn = (tile == 1 || tile == 4) ? 128 : 64;
     const long nblk = blocks(bm, bn);
     int splitk = 1;
     if (!geglu && p.partial != nullptr) {
@@ -454,7 +467,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     int stages = g_stages;
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
-        if (stages == 0) stages = tile == 3 ? 3 : 2;   // 128x128 / 128x64: 2 stages (2-3 blocks/CU); 64x64: 3 x 16 KiB
+        if (stages == 0) stages = (tile == 3 || tile == 4) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

@@ -18,6 +18,14 @@
 #include "lb_gemm.h"
 
 #define BK 64
+// Ablation builds for tools/gemm_ablate.py ONLY (never the shipped library): 1 = no global->LDS
+// requests, 2 = no LDS reads / MFMAs, 3 = MFMAs on register operands (no LDS reads).
+#ifndef LB_ABLATE
+#define LB_ABLATE 0
+#endif
+#ifndef LB_BURST            // 1 = the older loop body: all requests right after the barrier (A/B studies)
+#define LB_BURST 0
+#endif
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -25,12 +33,16 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, bool CONV, bool GEGLU, int S>
-__global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p) {
-    constexpr int AI = BM * 8 / 256;        // wave instructions (16-B chunks per thread) of A per K-tile
-    constexpr int WI = BN * 8 / 256;
+// WMW = waves along M (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along N
+template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW>
+__global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmParams p) {
+    constexpr int NT = WMW * 128;           // threads per block
+    constexpr int RPI = NT / 8;             // tile rows covered by one round of wave instructions
+    constexpr int AI = BM * 8 / NT;         // wave instructions (16-B chunks per thread) of A per K-tile
+    constexpr int WI = BN * 8 / NT;
     constexpr int NL = AI + WI;             // VMEM loads per thread per K-tile
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int WROWS = BM / WMW;         // rows of the block tile owned by one wave
+    constexpr int TM = WROWS / 16, TN = BN / 32;
     constexpr int STAGE = (BM + BN) * BK;   // halves per ring stage
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
 
@@ -73,7 +85,7 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
     int kcur = kt_begin * BK + cl * 8;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-        const int m = m0 + row0 + i * 32;
+        const int m = m0 + row0 + i * RPI;
         a_ok[i] = m < p.M;
         if (CONV) {
             const int hw = p.Hout * p.Wout;
@@ -97,7 +109,7 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
     bool w_ok[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int tr = row0 + i * 32;
+        const int tr = row0 + i * RPI;
         int n;
         if (GEGLU) {
             const int sub = tr >> 4;
@@ -112,13 +124,13 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
     const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
     const int hin_eff = p.Hin << p.ups, win_eff = p.Win << p.ups;
 
-    // request one K-tile into ring stage `st` (branch-free: masked chunks read the zero page)
-    auto issue_tile = [&](int st) {
-        f16* base = lds + st * STAGE;
-        const bool k_ok = kcur < k_end;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const lb_half* src;
+    // request number idx (0..NL-1: AI rows of A, then WI rows of W) of the current K-tile into the ring
+    // stage at `base` (branch-free: masked chunks read the zero page)
+    auto issue_one = [&](int idx, f16* base, bool k_ok) {
+        const lb_half* src;
+        f16* dst;
+        if (idx < AI) {
+            const int i = idx;
             if (CONV) {
                 const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
                 const bool ok = a_ok[i] && k_ok && iy >= 0 && iy < hin_eff && ix >= 0 && ix < win_eff;
@@ -127,15 +139,16 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
                 src = (a_ok[i] && k_ok) ? p.A + a_off[i] + kcur : zero;
             }
             // wave-uniform LDS base of this instruction's 8 rows; hardware adds lane * 16 B
-            f16* dst = base + (wave * 8 + i * 32) * BK;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            dst = base + (wave * 8 + i * RPI) * BK;
+        } else {
+            const int i = idx - AI;
+            src = (w_ok[i] && k_ok) ? p.W + w_off[i] + kcur : zero;
+            dst = base + BM * BK + (wave * 8 + i * RPI) * BK;
         }
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const lb_half* src = (w_ok[i] && k_ok) ? p.W + w_off[i] + kcur : zero;
-            f16* dst = base + BM * BK + (wave * 8 + i * 32) * BK;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        }
+        if (LB_ABLATE != 1) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+    // advance this thread's K position (and conv tap state) by one K-tile
+    auto advance_k = [&]() {
         kcur += BK;
         if (CONV) {
             ci += BK;
@@ -154,6 +167,13 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
             }
         }
     };
+    auto issue_tile = [&](int st) {
+        f16* base = lds + st * STAGE;
+        const bool k_ok = kcur < k_end;
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(idx, base, k_ok);
+        advance_k();
+    };
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -161,42 +181,88 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int st) {
-        const f16* Ab = lds + st * STAGE + (wave_m * (BM / 2)) * BK;
+    // operand fragments of K-half s of the tile in stage st
+    auto read_frags = [&](int st, int s, f16x8 (&af)[TM], f16x8 (&wf)[TN]) {
+        const f16* Ab = lds + st * STAGE + (wave_m * WROWS) * BK;
         const f16* Wb = lds + st * STAGE + BM * BK + (wave_n * (BN / 2)) * BK;
+        const int chunk = s * 4 + g;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 af[TM], wf[TN];
-            const int chunk = s * 4 + g;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r = i * 16 + l16;
-                af[i] = *reinterpret_cast<const f16x8*>(Ab + r * BK + ((chunk ^ (r & 7)) << 3));
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int r = j * 16 + l16;
-                wf[j] = *reinterpret_cast<const f16x8*>(Wb + r * BK + ((chunk ^ (r & 7)) << 3));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) {
+            const int r = i * 16 + l16;
+            if (LB_ABLATE == 3) { af[i] = (f16x8){(f16)lane, 1, 2, 3, 4, 5, 6, (f16)st}; continue; }
+            af[i] = *reinterpret_cast<const f16x8*>(Ab + r * BK + ((chunk ^ (r & 7)) << 3));
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = j * 16 + l16;
+            if (LB_ABLATE == 3) { wf[j] = (f16x8){(f16)st, 1, 2, 3, 4, 5, 6, (f16)lane}; continue; }
+            wf[j] = *reinterpret_cast<const f16x8*>(Wb + r * BK + ((chunk ^ (r & 7)) << 3));
+        }
+    };
+    auto mma_rows = [&](const f16x8 (&af)[TM], const f16x8 (&wf)[TN], int i_lo, int i_hi) {
+#pragma unroll
+        for (int i = i_lo; i < i_hi; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     };
 
     // ---- prologue: tiles 0 .. S-2 in flight ----
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) issue_tile(s);
 
+    // One K-tile per iteration.  The NL requests of tile t+S-1 are NOT issued in one burst after the
+    // barrier (all waves of a block would then sit in the VMEM issue queue together and start their
+    // MFMAs together): they are spread over the four MFMA groups of tile t, so a wave blocked on a
+    // full memory pipeline has MFMAs of its own still executing.  sched_barrier pins the order.
+    // (tools/gemm_ablate.py: 5-13 % on the plain / GEGLU contractions, first > 1 PFLOP/s at 8192^3.)
+    constexpr int HM = TM > 1 ? TM / 2 : 1;
     int st = 0;                               // ring stage of tile t
     for (int t = 0; t < nkt; ++t) {
         wait_vm_barrier<(S - 2) * NL>();      // tile t landed everywhere; stage (t-1)%S free everywhere
         int refill = st - 1;
         if (refill < 0) refill += S;
-        issue_tile(refill);                   // tile t+S-1 (masked to zeros past the end)
-        compute(st);
+        if (LB_ABLATE == 2) {
+            issue_tile(refill);
+        } else if (LB_BURST || (CONV && WMW == 2)) {   // 4-wave conv tiles measured 3-6 % faster with the burst
+            issue_tile(refill);               // tile t+S-1 (masked to zeros past the end)
+            f16x8 af[TM], wf[TN];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                read_frags(st, s, af, wf);
+                mma_rows(af, wf, 0, TM);
+            }
+        } else {
+            f16* base = lds + refill * STAGE;
+            const bool k_ok = kcur < k_end;
+            f16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+            read_frags(st, 0, a0, w0);
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx)
+                if (idx * 4 / NL == 0) issue_one(idx, base, k_ok);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rows(a0, w0, 0, HM);
+            read_frags(st, 1, a1, w1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx)
+                if (idx * 4 / NL == 1) issue_one(idx, base, k_ok);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rows(a0, w0, HM, TM);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx)
+                if (idx * 4 / NL == 2) issue_one(idx, base, k_ok);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rows(a1, w1, 0, HM);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx)
+                if (idx * 4 / NL == 3) issue_one(idx, base, k_ok);
+            advance_k();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_rows(a1, w1, HM, TM);
+        }
         st = st + 1 == S ? 0 : st + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before exit/epilogue
@@ -206,7 +272,7 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
         float* slab = p.partial + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wave_m * (BM / 2) + i * 16 + l16;
+            const int m = m0 + wave_m * WROWS + i * 16 + l16;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -218,7 +284,7 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wave_m * (BM / 2) + i * 16 + l16;
+        const int m = m0 + wave_m * WROWS + i * 16 + l16;
         if (m >= p.M) continue;
         const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
         if (GEGLU) {
@@ -246,25 +312,26 @@ __global__ void __launch_bounds__(256) gemm_f16_glds_kernel(const LbGemmParams p
     }
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int WMW = 2>
 static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t smem = (size_t)S * (BM + BN) * BK * sizeof(f16);
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
-    if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S>), grid, dim3(256), smem, stream, p);
-    else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S>), grid, dim3(256), smem, stream, p);
-    else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S>), grid, dim3(256), smem, stream, p);
+    const dim3 block(WMW * 128);
+    if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>), grid, block, smem, stream, p);
+    else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>), grid, block, smem, stream, p);
+    else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW>), grid, block, smem, stream, p);
     return 0;
 }
 
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside of any stream capture
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int WMW = 2>
 static void allow_lds() {
     const int smem = S * (BM + BN) * BK * (int)sizeof(f16);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 
@@ -272,15 +339,21 @@ void lb_gemm_glds_init() {
     static bool done = false;
     if (done) return;
     done = true;
-    allow_lds<128, 128, 2>(); allow_lds<128, 128, 3>();
+    allow_lds<128, 128, 2>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
     allow_lds<128, 64, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
     allow_lds<64, 64, 2>(); allow_lds<64, 64, 3>(); allow_lds<64, 64, 4>();
+    allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4>();
 }
 
-// tile: 1 = 128x128, 3 = 64x64 ; stages: 2..4 (0 = default for the tile)
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves); stages: 2..4 (0 = default for the tile)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
+    if (tile == 4) {
+        if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);
+        return launch_glds_variant<256, 128, 2, 4>(p, grid, stream);
+    }
     if (tile == 1) {
         if (stages == 2) return launch_glds_variant<128, 128, 2>(p, grid, stream);
+        if (stages == 4) return launch_glds_variant<128, 128, 4>(p, grid, stream);
         return launch_glds_variant<128, 128, 3>(p, grid, stream);
     }
     if (tile == 2) {

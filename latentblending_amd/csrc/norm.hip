@@ -14,7 +14,7 @@
 #include "lb_common.h"
 
 #define GN_MAX_GROUPS 32
-#define GN_MAX_CHUNKS 64
+#define GN_MAX_CHUNKS 256
 
 template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_type(8))); };
 
@@ -58,7 +58,22 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ x
         float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (active && v < vecs) {
             const T* base = x + ((long)b * HW) * ldx + v * 8;
-            for (int px = px_begin + r; px < px_end; px += rows) {
+            int px = px_begin + r;
+            for (; px + 3 * rows < px_end; px += 4 * rows) {     // four independent 16-B requests in flight
+                float v0[8], v1[8], v2[8], v3[8];
+                load8<T>(base + (long)px * ldx, v0);
+                load8<T>(base + (long)(px + rows) * ldx, v1);
+                load8<T>(base + (long)(px + 2 * rows) * ldx, v2);
+                load8<T>(base + (long)(px + 3 * rows) * ldx, v3);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s[e] += v0[e]; q[e] += v0[e] * v0[e];
+                    s[e] += v1[e]; q[e] += v1[e] * v1[e];
+                    s[e] += v2[e]; q[e] += v2[e] * v2[e];
+                    s[e] += v3[e]; q[e] += v3[e] * v3[e];
+                }
+            }
+            for (; px < px_end; px += rows) {
                 float val[8];
                 load8<T>(base + (long)px * ldx, val);
 #pragma unroll
@@ -95,15 +110,27 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
                                                        int ldy, int groups, int nchunk, float eps,
                                                        int silu) {
     __shared__ float mean_s[GN_MAX_GROUPS], rstd_s[GN_MAX_GROUPS];
+    __shared__ double fold_s[8][GN_MAX_GROUPS], fold_q[8][GN_MAX_GROUPS];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / groups;
+    {   // fold the chunk partials of this sample: 8 interleaved subsets per group, then a fixed-order sum
+        const int grp = tid & 31, sub = tid >> 5;
+        if (grp < groups) {
+            double s = 0, q = 0;
+            for (int c = sub; c < nchunk; c += 8) {
+                const double* pp = partial + (((long)b * nchunk + c) * groups + grp) * 2;
+                s += pp[0];
+                q += pp[1];
+            }
+            fold_s[sub][grp] = s;
+            fold_q[sub][grp] = q;
+        }
+    }
+    __syncthreads();
     if (tid < groups) {
         double s = 0, q = 0;
-        for (int c = 0; c < nchunk; ++c) {
-            const double* pp = partial + (((long)b * nchunk + c) * groups + tid) * 2;
-            s += pp[0];
-            q += pp[1];
-        }
+#pragma unroll
+        for (int sub = 0; sub < 8; ++sub) { s += fold_s[sub][tid]; q += fold_q[sub][tid]; }
         const double cnt = (double)HW * cpg;
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
@@ -114,12 +141,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
     __syncthreads();
     const int vecs = C >> 3;
     const long items = (long)HW * vecs;
-    for (long i = (long)blockIdx.x * 256 + tid; i < items; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    auto finish = [&](const float (&val)[8], long i) {
         const int px = (int)(i / vecs);
-        const int v = (int)(i - (long)px * vecs);
-        const int c0 = v * 8;
-        float val[8];
-        load8<T>(x + ((long)b * HW + px) * ldx + c0, val);
+        const int c0 = (int)(i - (long)px * vecs) * 8;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0);
         const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0);
@@ -138,6 +163,27 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
             o[e] = (f16)t;
         }
         *reinterpret_cast<f16x8*>(y + ((long)b * HW + px) * ldy + c0) = o;
+    };
+    auto src = [&](long i) {
+        const long px = i / vecs;
+        return x + ((long)b * HW + px) * ldx + (i - px * vecs) * 8;
+    };
+    long i = (long)blockIdx.x * 256 + tid;
+    for (; i + 3 * stride < items; i += 4 * stride) {          // four independent 16-B requests in flight
+        float v0[8], v1[8], v2[8], v3[8];
+        load8<T>(src(i), v0);
+        load8<T>(src(i + stride), v1);
+        load8<T>(src(i + 2 * stride), v2);
+        load8<T>(src(i + 3 * stride), v3);
+        finish(v0, i);
+        finish(v1, i + stride);
+        finish(v2, i + 2 * stride);
+        finish(v3, i + 3 * stride);
+    }
+    for (; i < items; i += stride) {
+        float val[8];
+        load8<T>(src(i), val);
+        finish(val, i);
     }
 }
 
@@ -152,9 +198,12 @@ static int groupnorm_impl(const void* x, void* y, const float* gamma, const floa
     LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "lb_groupnorm_nhwc: C/ld multiple of 8");
     LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_nhwc: groups");
     const int vecs = C / 8;
-    int chunk_px = (HW + GN_MAX_CHUNKS - 1) / GN_MAX_CHUNKS;
+    // ~2048 statistic blocks per launch (8 per CU), at least 32 pixels and at most GN_MAX_CHUNKS chunks per sample
+    int want = (2048 + B - 1) / B;
+    if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+    if (want < 16) want = 16;
+    int chunk_px = (HW + want - 1) / want;
     if (chunk_px < 32) chunk_px = 32;
-    if (HW >= 4096 && chunk_px < 128) chunk_px = 128;
     const int nchunk = (HW + chunk_px - 1) / chunk_px;
     double* partial = (double*)workspace;
     const int vpt = vecs <= 256 ? 1 : 2;

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must be imported first: shares libamdhip64 with the extension)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbhip.so")
+# LB_HIP_LIBRARY: an alternate build of the SAME library (kernel ablation studies, tools/gemm_ablate.py)
+LIB_PATH = os.environ.get("LB_HIP_LIBRARY") or os.path.join(_HERE, "liblbhip.so")
 
 c_void_pp = C.POINTER(C.c_void_p)
 

@@ -428,7 +428,7 @@ def test_small_kernels(results_log):
 
 # ------------------------------------------------------------------ direct-to-LDS GEMM variant
 @pytest.mark.parametrize("stages", [2, 3, 4])
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_gemm_glds_variant(tile, stages, results_log):
     """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references."""
     o, l = ops(), lib()
@@ -472,7 +472,7 @@ def test_gemm_glds_variant(tile, stages, results_log):
             got = o.gemm(xn.to(DEV), wp.to(DEV), bias=bp.to(DEV), conv=dict(KH=k, KW=k, stride=st, pad=pad, ups=ups))
             check_close(results_log, f"glds_conv_{'_'.join(map(str, case))}_t{tile}s{stages}", got[..., :Cout], ref)
     finally:
-        l.api.lb_gemm_set_variant(0, 0)
+        l.api.lb_gemm_set_variant(-1, 0)
         l.api.lb_gemm_set_tuning(0, 0)
 
 

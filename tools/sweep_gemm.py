@@ -11,12 +11,16 @@ from latentblending_amd.hip import lib
 from latentblending_amd.native.runtime import Program
 
 DEV, REP = "cuda", 20
+BIG_ONLY = "--big" in sys.argv      # only the big-M shapes, direct-to-LDS variants (256x128 tile study)
 
 
 def time_variant(p, tile, depth, splitk, glds_stages=0):
     lib.api.lb_gemm_set_tuning(tile, splitk)
     lib.api.lb_gemm_set_depth(depth)
-    lib.api.lb_gemm_set_variant(1 if glds_stages else 0, glds_stages)
+    if tile == 0 and depth == 0 and not glds_stages:
+        lib.api.lb_gemm_set_variant(-1, 0)          # the library's own choice
+    else:
+        lib.api.lb_gemm_set_variant(1 if glds_stages else 0, glds_stages)
     prog = Program("sweep")
     try:
         with prog.record():
@@ -25,7 +29,7 @@ def time_variant(p, tile, depth, splitk, glds_stages=0):
     finally:
         lib.api.lb_gemm_set_tuning(0, 0)
         lib.api.lb_gemm_set_depth(0)
-        lib.api.lb_gemm_set_variant(0, 0)
+        lib.api.lb_gemm_set_variant(-1, 0)
     prog.instantiate()
     st = torch.cuda.current_stream().cuda_stream
     prog.launch(st)
@@ -41,7 +45,7 @@ def time_variant(p, tile, depth, splitk, glds_stages=0):
 
 def main():
     shapes = []
-    for B in (2, 15):
+    for B in (2, 17):
         M3, M2 = 256 * B, 1024 * B
         shapes += [("lin", M3, 1280, 1280), ("lin", M3, 2560, 1280), ("lin", M3, 1280, 5120), ("geglu", M3, 10240, 1280),
                    ("lin", 1280, M3, 1280), ("lin", M2, 640, 640), ("geglu", M2, 5120, 640), ("lin", M2, 640, 2560),
@@ -49,6 +53,8 @@ def main():
                    ("conv", (B, 16, 2560, 1280)), ("conv", (B, 32, 1280, 640))]
     shapes += [("conv", (1, 64, 512, 512)), ("conv", (1, 128, 512, 512)), ("conv", (1, 256, 256, 256)), ("conv", (1, 512, 128, 128)),
                ("conv", (8, 512, 128, 128)), ("lin", 4096, 4096, 4096), ("lin", 8192, 8192, 8192)]
+    if BIG_ONLY:
+        shapes = [sh for sh in shapes if (sh[0] == "conv" and sh[1][0] * sh[1][1] ** 2 >= 8192) or (sh[0] != "conv" and sh[1] >= 3840)]
     results = []
     for sh in shapes:
         p = lib.LbGemmParams()
@@ -78,9 +84,11 @@ def main():
         row = {"shape": tag, "variants": {}}
         zp = torch.zeros(64, dtype=torch.uint8, device=DEV)
         p.zero_page = zp.data_ptr()
-        for tile in (1, 2, 3):
+        for tile in (1, 2, 3, 4):
             for mode, val in [("d", 1), ("d", 3), ("d", 4), ("g", 2), ("g", 3), ("g", 4)]:
-                if tile == 1 and mode == "g" and val == 4:
+                if tile == 4 and (mode == "d" or val == 4):     # 256x128 lives in the direct-to-LDS family, 2-3 stages
+                    continue
+                if BIG_ONLY and mode == "d":
                     continue
                 for sk in ([0] if not small or sh[0] == "geglu" else [1, 0]):
                     p.partial = ws.data_ptr() if (small and sh[0] != "geglu" and sk != 1) else None
