@@ -338,11 +338,15 @@ static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     }
 }
 
-static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64 4=256x128 (direct-to-LDS only)
+static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64, direct-to-LDS only: 4=256x128 5=256x256
 static int g_force_splitk = 0;    // 0 auto
 static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
 extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
+// A/B studies of the tile policy (tools/ab_policy.py): bit 0 no 256x128, bit 1 no 256x256, bit 2 no
+// 256x256 for convolutions, bit 3 no 256x256 for plain/GEGLU, bit 4 no 256x128 for convolutions
+static int g_policy_off = 0;
+extern "C" void lb_gemm_set_policy(int disable_mask) { g_policy_off = disable_mask; }
 
 // direct-to-LDS variant (gemm_glds.hip)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream);
@@ -441,11 +445,18 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
             const int unit = geglu ? 64 : 128;
             const int n_pad = (n_eff + unit - 1) / unit * unit;
             const bool n_fits = (long)n_pad * 10 <= (long)n_eff * 11;           // <= 10 % padded columns
-            if (n_fits && (b256 >= 1024 || (!p.conv && b256 >= 160 && p.K >= 1024))) tile = 4;
+            const bool allow4 = !(g_policy_off & 1) && !(p.conv && (g_policy_off & 16));
+            const bool allow5 = !(g_policy_off & 2) && !(p.conv ? (g_policy_off & 4) : (g_policy_off & 8));
+            if (allow4 && n_fits && (b256 >= 1024 || (!p.conv && b256 >= 160 && p.K >= 1024))) tile = 4;
+            // 256x256 (64x128 per wave, two 64 KiB stages): half the operand bytes per FLOP of 128x128.
+            // Measured cost per tile = 1.74 x a 256x128 tile; taken when that saves rounds over the chip.
+            const long b512 = blocks(256, 256);
+            const long rounds4 = (b256 + 255) / 256, rounds5 = (b512 + 255) / 256;
+            if (allow5 && (b512 >= 1024 || (b512 >= 160 && p.K >= 1024)) && rounds5 * 174 < rounds4 * 100) tile = 5;
         }
     }
-    if (tile == 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 256x128: direct-to-LDS family only
-    const int bm = tile == 4 ? 256 : (tile == 3 ? 64 : 128), bn = (tile == 1 || tile == 4) ? 128 : 64;
+    if (tile >= 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 8-wave tiles: direct-to-LDS family only
+    const int bm = tile >= 4 ? 256 : (tile == 3 ? 64 : 128), bn = tile == 5 ? 256 : ((tile == 1 || tile == 4) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
     if (!geglu && p.partial != nullptr) {

@@ -343,10 +343,12 @@ void lb_gemm_glds_init() {
     allow_lds<128, 64, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
     allow_lds<64, 64, 2>(); allow_lds<64, 64, 3>(); allow_lds<64, 64, 4>();
     allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4>();
+    allow_lds<256, 256, 2, 4>();
 }
 
-// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves); stages: 2..4 (0 = default for the tile)
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave); stages: 2..4 (0 = default for the tile)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
+    if (tile == 5) return launch_glds_variant<256, 256, 2, 4>(p, grid, stream);     // 128 KiB: two stages only
     if (tile == 4) {
         if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);
         return launch_glds_variant<256, 128, 2, 4>(p, grid, stream);

@@ -84,8 +84,10 @@ def main():
         row = {"shape": tag, "variants": {}}
         zp = torch.zeros(64, dtype=torch.uint8, device=DEV)
         p.zero_page = zp.data_ptr()
-        for tile in (1, 2, 3, 4):
+        for tile in (1, 2, 3, 4, 5):
             for mode, val in [("d", 1), ("d", 3), ("d", 4), ("g", 2), ("g", 3), ("g", 4)]:
+                if tile == 5 and not (mode == "g" and val == 2):
+                    continue
                 if tile == 4 and (mode == "d" or val == 4):     # 256x128 lives in the direct-to-LDS family, 2-3 stages
                     continue
                 if BIG_ONLY and mode == "d":
