@@ -282,34 +282,8 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
         }
         return;
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wave_m * WROWS + i * 16 + l16;
-        if (m >= p.M) continue;
-        const int bidx = p.rowvec ? m / p.rows_per_batch : 0;
-        if (GEGLU) {
-#pragma unroll
-            for (int j = 0; j < TN; j += 2) {
-                const int n = n0 + (wave_n * (BN / 64) + (j >> 1)) * 16 + 4 * g;
-                if (n >= p.N / 2) continue;
-                f16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float h = acc[i][j][r] * p.alpha, gt = acc[i][j + 1][r] * p.alpha;
-                    if (p.bias) { h += p.bias[n + r]; gt += p.bias[p.N / 2 + n + r]; }
-                    o[r] = (f16)(h * lb_gelu_erf(gt));
-                }
-                *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) = o;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wave_n * (BN / 2) + j * 16 + 4 * g;
-                if (n >= p.N) continue;
-                lb_gemm_store4(p, m, n, bidx, acc[i][j]);
-            }
-        }
-    }
+    lb_gemm_tile_epilogue<TM, TN, GEGLU>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
+                                         n0 + wave_n * (BN / 64) * 16 + 4 * g);
 }
 
 template <int BM, int BN, int S, int WMW = 2>

@@ -56,3 +56,127 @@ __device__ __forceinline__ void lb_gemm_store4(const LbGemmParams& p, int m, int
             (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Tile epilogue shared by both GEMM kernels.  Lane (g = lane>>4, l16 = lane&15) of a wave owns rows
+// row0 + 16 i (i < TM; row0 already contains l16) and the 4-column groups col0 + 16 j (j < TN; col0
+// already contains 4 g).  Every global load of a row (bias, residual, time-embedding row vector) is
+// issued branch-free, with clamped addresses, BEFORE the first dependent store: with divergent `continue`s around the loads the compiler must keep each 4-output group's
+// load -> wait -> store chain separate, i.e. one memory round trip per group (measured in situ: +30 % on
+// the residual / bias GEMMs of the UNet against the same launches without epilogue operands).
+// GEGLU: accumulator column pairs (2 jp, 2 jp + 1) are (h, gate) of output column gcol0 + 16 jp.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lb_gemm_write4(const LbGemmParams& p, long crow, int m, int n, const float (&o)[4]) {
+    if (p.flags & LB_GEMM_TRANS_OUT) {
+        f16* c = (f16*)p.C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[(long)(n + r) * p.ldc + m] = (f16)o[r];
+    } else if (p.flags & LB_GEMM_OUT_F32) {
+        *reinterpret_cast<f32x4*>((float*)p.C + crow * p.ldc + n) = (f32x4){o[0], o[1], o[2], o[3]};
+    } else {
+        *reinterpret_cast<f16x4*>((f16*)p.C + crow * p.ldc + n) =
+            (f16x4){(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+    }
+}
+
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void lb_gemm_tile_epilogue(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
+                                                      int row0, int col0, int gcol0) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (GEGLU) {
+        constexpr int TP = TN / 2 > 0 ? TN / 2 : 1;
+        const int half = p.N / 2;
+        f32x4 bh[TP], bg[TP];
+#pragma unroll
+        for (int jp = 0; jp < TP; ++jp) {
+            const int n = gcol0 + jp * 16;
+            const int nc = n < half ? n : 0;
+            bh[jp] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : zero4;
+            bg[jp] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + half + nc) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = row0 + i * 16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int jp = 0; jp < TP; ++jp) {
+                const int n = gcol0 + jp * 16;
+                if (n >= half) continue;
+                f16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float h = acc[i][2 * jp][r] * p.alpha + bh[jp][r];
+                    const float gt = acc[i][(2 * jp + 1) % TN][r] * p.alpha + bg[jp][r];
+                    o[r] = (f16)(h * lb_gelu_erf(gt));
+                }
+                *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = row0 + i * 16;
+        const bool m_ok = m < p.M;
+        const int mc = m_ok ? m : p.M - 1;
+        f32x4 add[TN];                  // bias + row vector + residual of this row's TN column groups
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {  // (re-read per row: L1 hits in the same request batch, no registers held)
+            const int n = col0 + j * 16;
+            add[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + (n < p.N ? n : 0)) : zero4;
+        }
+        if (p.rowvec) {
+            const f16* rv = reinterpret_cast<const f16*>(p.rowvec) + (long)(mc / p.rows_per_batch) * p.ld_rowvec;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = col0 + j * 16;
+                const f16x4 t = *reinterpret_cast<const f16x4*>(rv + (n < p.N ? n : 0));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) add[j][r] += (float)t[r];
+            }
+        }
+        if (p.residual) {
+            if (p.flags & LB_GEMM_RES_F32) {
+                const float* rr = (const float*)p.residual + (long)mc * p.ldr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = col0 + j * 16;
+                    add[j] += *reinterpret_cast<const f32x4*>(rr + (n < p.N ? n : 0));
+                }
+            } else {
+                const f16* rr = (const f16*)p.residual + (long)mc * p.ldr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = col0 + j * 16;
+                    const f16x4 q = *reinterpret_cast<const f16x4*>(rr + (n < p.N ? n : 0));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) add[j][r] += (float)q[r];
+                }
+            }
+        }
+        long crow = m;                  // output row; sub-pixel convs scatter to the 2x-upsampled grid
+        if (p.scatter) {
+            const int hw = p.Hout * p.Wout;
+            const int b = mc / hw, rem = mc - b * hw;
+            const int y = rem / p.Wout, x = rem - y * p.Wout;
+            crow = ((long)b * 2 * p.Hout + 2 * y + p.sc_py) * (2 * p.Wout) + 2 * x + p.sc_px;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = col0 + j * 16;
+            if (!m_ok || n >= p.N) continue;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r] * p.alpha + add[j][r];
+            if (p.flags & LB_GEMM_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = lb_silu(o[r]);
+            }
+            if (p.flags & LB_GEMM_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+            }
+            lb_gemm_write4(p, crow, m, n, o);
+        }
+    }
+}

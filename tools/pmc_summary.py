@@ -22,7 +22,7 @@ def family(name):
 
 
 out = {}
-stats = glob.glob("gpurun_out/rocprof_r1h/*kernel_stats.csv")
+stats = glob.glob("gpurun_out/rocprof_final/**/*kernel_stats.csv", recursive=True) or glob.glob("gpurun_out/rocprof_final/*kernel_stats.csv")
 if stats:
     fam = collections.defaultdict(lambda: [0.0, 0])
     with open(stats[0]) as fh:
@@ -35,7 +35,7 @@ if stats:
                                         "share": v[0] / total} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
 pmc = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(f"gpurun_out/pmc_{counter}/*counter_collection.csv")
+    files = glob.glob(f"gpurun_out/pmc_{counter}/**/*counter_collection.csv", recursive=True)
     if not files:
         continue
     tot, n = 0.0, 0
