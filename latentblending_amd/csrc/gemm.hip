@@ -430,13 +430,20 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         }
     }
     if (tile >= 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 8-wave tiles: direct-to-LDS family only
+    // long-K problems with 1-2.5 small tiles per CU (B=2 convs of the UNet: M=2048, N=640, K=5760): no split
+    // is possible at 64x64 (> 256 blocks), so they crawl through ~90 K-tiles per block.  Take 128x64 tiles
+    // (half the blocks) and let the split-K rule below spread K instead.
+    if (!g_force_tile && tile == 3 && !geglu && p.partial != nullptr && (p.K + BK - 1) / BK >= 64) {
+        const long b64 = blocks(64, 64);
+        if (b64 > 256 && b64 <= 640 && blocks(128, 64) <= 256) tile = 2;
+    }
     const int bm = tile >= 4 ? 256 : (tile == 3 ? 64 : 128), bn = tile == 5 ? 256 : ((tile == 1 || tile == 4) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
     if (!geglu && p.partial != nullptr) {
         const int k_tiles = (p.K + BK - 1) / BK;
         if (g_force_splitk) splitk = g_force_splitk;
-        else if (nblk < 160) {
+        else if (nblk <= 256) {
             // long-K, few-tile problems (M = 256..512 rows against K up to 23040): aim at ~2.5 blocks
             // per CU but keep >= 16 K-tiles per slice so the slab round trip stays negligible
             splitk = (int)((640 + nblk - 1) / nblk);

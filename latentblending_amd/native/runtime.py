@@ -140,10 +140,10 @@ class Emitter:
 
     # -- workspaces -------------------------------------------------------------------------
     def _gemm_ws(self, M: int, N: int) -> Optional[torch.Tensor]:
-        """Split-K slab region.  The launcher only splits grids of fewer than 160 64x64 tiles, so
-        larger problems get no workspace (and cannot split).  A grown workspace never replaces the
+        """Split-K slab region.  The launcher only splits grids of at most 640 64x64 tiles (<= 256 blocks of
+        the tile it then picks), so larger problems get no workspace (and cannot split).  A grown workspace never replaces the
         old one in already-recorded ops: superseded buffers are kept alive."""
-        if ((M + 63) // 64) * ((N + 63) // 64) >= 160:
+        if ((M + 63) // 64) * ((N + 63) // 64) > 640:
             return None
         need = api.lb_gemm_workspace_bytes(M, N) // 4
         if self.ws_gemm is None or self.ws_gemm.numel() < need:

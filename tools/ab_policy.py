@@ -24,7 +24,7 @@ def replay_ms(launch, reps):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 17
-    masks = [int(a) for a in sys.argv[2:]] or [0, 2, 4, 8, 1 | 2, 16]
+    masks = [int(a) for a in sys.argv[2:] if not a.startswith("--")] or [0, 2, 4, 8, 1 | 2, 16]
     pipe = N.NativeSDXLPipe(turbo=True)
     for mask in masks:
         lib.api.lb_gemm_set_policy(mask)
@@ -34,6 +34,9 @@ def main():
         up.forward(torch.randn(B, 4, 64, 64, device="cuda").half(), torch.full((B,), 499.0))
         up.enable_graphs()
         t_u = replay_ms(up.prog_step.launch, 10)
+        if "--unet-only" in sys.argv:
+            print(f"policy mask {mask:2d}: UNet B={B} {t_u:8.3f} ms", flush=True)
+            continue
         vp = pipe.vae_native.build(B, 64)
         vp.decode(torch.randn(B, 4, 64, 64, device="cuda").half())
         vp.prog.instantiate()

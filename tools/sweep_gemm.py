@@ -53,6 +53,8 @@ def main():
                    ("conv", (B, 16, 2560, 1280)), ("conv", (B, 32, 1280, 640))]
     shapes += [("conv", (1, 64, 512, 512)), ("conv", (1, 128, 512, 512)), ("conv", (1, 256, 256, 256)), ("conv", (1, 512, 128, 128)),
                ("conv", (8, 512, 128, 128)), ("lin", 4096, 4096, 4096), ("lin", 8192, 8192, 8192)]
+    if "--small" in sys.argv:
+        shapes = [sh for sh in shapes if (sh[0] == "conv" and sh[1][0] == 2 and sh[1][1] <= 32) or (sh[0] == "lin" and sh[1] <= 512)]
     if BIG_ONLY:
         shapes = [sh for sh in shapes if (sh[0] == "conv" and sh[1][0] * sh[1][1] ** 2 >= 8192) or (sh[0] != "conv" and sh[1] >= 3840)]
     results = []
@@ -79,7 +81,7 @@ def main():
         p.M, p.N, p.K, p.ldw, p.ldc = M, N, K, K, out.shape[-1]
         ws = torch.empty(min(lib.api.lb_gemm_workspace_bytes(M, N) // 4, 1 << 28), dtype=torch.float32, device=DEV)
         flops = 2.0 * M * N * K
-        small = ((M + 63) // 64) * ((N + 63) // 64) < 160
+        small = ((M + 63) // 64) * ((N + 63) // 64) <= 640
         best = None
         row = {"shape": tag, "variants": {}}
         zp = torch.zeros(64, dtype=torch.uint8, device=DEV)
