@@ -7,6 +7,8 @@ from .diffusers_holder import DiffusersHolder
 from .utils import (interpolate_spherical, add_frames_linear_interp, interpolate_linear,
                     get_spacing, get_time, yml_load, yml_save)
 
-__all__ = ["BlendingEngine", "DiffusersHolder", "interpolate_spherical",
+from . import replay  # noqa: E402  (multi-transition driver + movie JSON)
+
+__all__ = ["BlendingEngine", "replay", "DiffusersHolder", "interpolate_spherical",
            "add_frames_linear_interp", "interpolate_linear", "get_spacing", "get_time",
            "yml_load", "yml_save"]

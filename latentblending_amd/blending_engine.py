@@ -677,7 +677,7 @@ class BlendingEngine:
             return pipe.native_frame_distances([(imgA, imgB)])[0]
 
         def to_tensor(img):
-            t = torch.from_numpy(np.asarray(img)).float()
+            t = torch.from_numpy(np.array(img)).float()           # (copy: PIL buffers are read-only)
             t = t.cuda(self.device) if str(self.device).startswith("cuda") else t
             t = 2 * t / 255.0 - 1
             return t.permute([2, 0, 1]).unsqueeze(0)

@@ -19,7 +19,10 @@ from PIL import Image
 from .utils import add_frames_linear_interp
 
 try:  # pragma: no cover - not installed in the build image
-    from lunar_tools import MovieSaver, fill_up_frames_linear_interpolation  # type: ignore
+    import lunar_tools as _lt  # type: ignore
+    if getattr(_lt, "__lb_facade__", False):      # the repo-root facade forwards to THIS module
+        raise ImportError("lunar_tools facade")
+    from lunar_tools import MovieSaver, fill_up_frames_linear_interpolation, concatenate_movies  # type: ignore
     HAVE_LUNAR_TOOLS = True
 except Exception:
     HAVE_LUNAR_TOOLS = False
@@ -76,3 +79,46 @@ except Exception:
             body = b"AVI " + hdrl + riff_list(b"movi", movi_body) + chunk(b"idx1", index)
             with open(self.fp_out, "wb") as fh:
                 fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+    def read_movie_jpegs(fp_movie: str) -> List[bytes]:
+        """JPEG payloads of the ``00dc`` chunks of an MJPEG-AVI written by :class:`MovieSaver`."""
+        with open(fp_movie, "rb") as fh:
+            data = fh.read()
+        if data[:4] != b"RIFF" or data[8:12] != b"AVI ":
+            raise ValueError(f"{fp_movie}: not an AVI written by latentblending_amd.movie.MovieSaver")
+        pos, out = 12, []
+        while pos + 8 <= len(data):
+            tag, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+            if tag == b"LIST":
+                if data[pos + 8:pos + 12] == b"movi":
+                    q, end = pos + 12, pos + 8 + size
+                    while q + 8 <= end:
+                        t2, s2 = data[q:q + 4], struct.unpack("<I", data[q + 4:q + 8])[0]
+                        if t2 == b"00dc":
+                            out.append(data[q + 8:q + 8 + s2])
+                        q += 8 + s2 + (s2 & 1)
+                pos += 8 + size + (size & 1)
+            else:
+                pos += 8 + size + (size & 1)
+        return out
+
+    def read_movie_header(fp_movie: str):
+        """(fps, height, width, number of frames) of an AVI written by :class:`MovieSaver`."""
+        with open(fp_movie, "rb") as fh:
+            data = fh.read(256)
+        i = data.index(b"avih")
+        v = struct.unpack("<14I", data[i + 8:i + 8 + 56])
+        return int(round(1e6 / v[0])), v[9], v[8], v[4]
+
+    def concatenate_movies(fp_final: str, list_fp_movies: List[str]) -> None:
+        """``lunar_tools.concatenate_movies(fp_final, parts)`` (reference: example_multi_trans.py:62): the
+        parts' frames back to back in one file.  JPEG payloads are copied, not re-encoded."""
+        assert len(list_fp_movies) > 0, "concatenate_movies: empty list"
+        fps, h, w, _ = read_movie_header(list_fp_movies[0])
+        saver = MovieSaver(fp_final, fps=fps, shape_hw=[h, w])
+        for fp in list_fp_movies:
+            f2, h2, w2, _ = read_movie_header(fp)
+            assert (f2, h2, w2) == (fps, h, w), f"{fp}: fps/size differ from the first part"
+            saver._jpegs.extend(read_movie_jpegs(fp))
+        saver.finalize()

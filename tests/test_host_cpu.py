@@ -377,3 +377,91 @@ def test_host_utilities_and_movie_writer(tmp_path):
     saver.finalize()
     blob = open(tmp_path / "m.avi", "rb").read()
     assert blob[:4] == b"RIFF" and blob[8:12] == b"AVI " and blob.count(b"00dc") >= 10
+
+
+def test_movie_concatenation_and_lunar_tools_facade(tmp_path):
+    """lunar_tools.concatenate_movies stand-in (example_multi_trans.py:62): parts back to back, payloads kept."""
+    import lunar_tools
+    from latentblending_amd import movie
+    assert lunar_tools.MovieSaver is movie.MovieSaver and lunar_tools.concatenate_movies is movie.concatenate_movies
+    with pytest.raises(AttributeError):
+        lunar_tools.SomethingElse
+    parts = []
+    for k, n in enumerate((3, 5)):
+        fp = str(tmp_path / f"p{k}.mp4")
+        s = movie.MovieSaver(fp, fps=7, shape_hw=[16, 24])
+        for i in range(n):
+            s.write_frame(np.full((16, 24, 3), 40 * k + 10 * i, dtype=np.uint8))
+        s.finalize()
+        parts.append(fp)
+        assert movie.read_movie_header(fp) == (7, 16, 24, n)
+    fp_all = str(tmp_path / "all.mp4")
+    lunar_tools.concatenate_movies(fp_all, parts)
+    assert movie.read_movie_header(fp_all) == (7, 16, 24, 8)
+    jp = movie.read_movie_jpegs(fp_all)
+    assert jp == movie.read_movie_jpegs(parts[0]) + movie.read_movie_jpegs(parts[1])
+    from PIL import Image
+    import io
+    means = [float(np.asarray(Image.open(io.BytesIO(j))).mean()) for j in jp]
+    assert np.allclose(means, [0, 10, 20, 40, 50, 60, 70, 80], atol=1.5)
+    bad = str(tmp_path / "other.mp4")
+    s = movie.MovieSaver(bad, fps=9, shape_hw=[16, 24]); s.write_frame(np.zeros((16, 24, 3), np.uint8)); s.finalize()
+    with pytest.raises(AssertionError):
+        movie.concatenate_movies(fp_all, [parts[0], bad])
+
+
+def test_multi_transition_driver_and_movie_json(tmp_path, cpu_backend):
+    """replay.run_movie_json == the loop of example_multi_trans_json.py:47-71 written out by hand: same
+    engine calls, same frames, every shared key frame diffused once, one part per segment + the final movie."""
+    from latentblending_amd import BlendingEngine, replay
+    from latentblending_amd import movie
+
+    def engine():
+        p = tiny_pipe(turbo=True)
+        np.random.seed(0)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+        be.set_branching(nmb_max_branches=3)
+        return p, be
+
+    prompts = ["a reef", "an alien planet", "a city at night"]
+    negs = ["blurry", "pale", "lofi"]
+    seeds = [11, 12, 13]
+    # the file the UI would have written (gradio_ui.py:168-190)
+    p0, be0 = engine()
+    be0.set_dimensions((128, 128)); be0.set_num_inference_steps(4)
+    fp_json = str(tmp_path / "movie.json")
+    replay.save_movie_json(fp_json, be0, [{"iteration": i, "seed": seeds[i], "prompt": prompts[i],
+                                           "negative_prompt": negs[i], "preview_image": None} for i in range(3)])
+    header, items = replay.load_movie_json(fp_json)
+    assert header == {"settings": "sdxl", "width": 128, "height": 128, "num_inference_steps": 4} and len(items) == 3
+    # by hand, as the reference script does it
+    p1, be1 = engine()
+    be1.set_dimensions((128, 128)); be1.set_num_inference_steps(4)
+    hand = []
+    for i in range(2):
+        if i == 0:
+            be1.set_prompt1(prompts[0]); be1.set_negative_prompt(negs[0]); be1.set_prompt2(prompts[1])
+        else:
+            be1.swap_forward(); be1.set_negative_prompt(negs[i + 1]); be1.set_prompt2(prompts[i + 1])
+        hand.append([np.asarray(f) for f in be1.run_transition(recycle_img1=i > 0, fixed_seeds=seeds[i:i + 2])])
+    # through the driver
+    p2, be2 = engine()
+    fp_movie = str(tmp_path / "out.mp4")
+    segs = replay.run_movie_json(be2, fp_json, fp_movie, duration_single_trans=1, fps=6, dp_parts=str(tmp_path))
+    assert len(segs) == 2 and p2.unet.calls == p1.unet.calls and p2.vae.calls == p1.vae.calls
+    for a, b in zip(hand, segs):
+        assert len(a) == len(b) == 5
+        for x, y in zip(a, b):
+            assert np.array_equal(x, np.asarray(y))
+    assert np.array_equal(np.asarray(segs[0][-1]), np.asarray(segs[1][0]))          # shared key frame, recycled
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("tmp_part_")) == ["tmp_part_000.mp4", "tmp_part_001.mp4"]
+    assert movie.read_movie_header(fp_movie) == (6, 128, 128, 12)
+    # argument checking
+    with pytest.raises(ValueError):
+        replay.run_multi_transition(be2, ["only one"], [1])
+    with pytest.raises(ValueError):
+        replay.run_multi_transition(be2, prompts, [1, 2])
+    bad = str(tmp_path / "bad.json")
+    json.dump([{"foo": 1}], open(bad, "w"))
+    with pytest.raises(ValueError):
+        replay.load_movie_json(bad)
