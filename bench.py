@@ -97,6 +97,45 @@ def gemm_family_profile(pipe, launches):
     return tot
 
 
+def install_launch_counters(pipe, counts):
+    """Wrap the launch method of every recorded UNet step / VAE program so that `counts` ends up holding
+    {("unet"|"vae", B, L): launches}.  A dict increment per PROGRAM launch (5 per transition): not measurable."""
+    for key, prog in pipe._unet_programs.items():
+        orig = prog.prog_step.launch
+
+        def counted(stream=None, _o=orig, _k=key):
+            counts[("unet",) + _k] = counts.get(("unet",) + _k, 0) + 1
+            return _o(stream)
+        prog.prog_step.launch = counted
+    for key, prog in pipe._vae_programs.items():
+        orig = prog.prog.launch
+
+        def counted_v(stream=None, _o=orig, _k=key):
+            counts[("vae",) + _k] = counts.get(("vae",) + _k, 0) + 1
+            return _o(stream)
+        prog.prog.launch = counted_v
+
+
+def roofline_block(prof, launch_counts):
+    achieved = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] else 0.0
+    return {
+        "bound": "mfma", "kernel": "gemm_f16_glds_kernel<BM,BN,CONV,GEGLU,S,WMW> (all Linear/Conv of UNet+VAE)",
+        "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
+        "traffic": _pmc_traffic_per_launch(),
+        "traffic_unit": "HBM-side bytes per GEMM launch (rocprofv3 PMC passes committed in profiles/; null if absent)",
+        "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
+        "algorithmic_tflop_per_transition_reference": 103.1,
+        "per_transition": {"gemm_tflop": prof["gemm_flops"] / 1e12, "gemm_ms": prof["gemm_ms"],
+                           "gemm_launches": prof["gemm_launches"],
+                           "gemm_avg_us_per_launch": prof["gemm_ms"] * 1e3 / max(prof["gemm_launches"], 1),
+                           "gemm_algorithmic_GBs": prof["gemm_bytes"] / (prof["gemm_ms"] * 1e-3) / 1e9 if prof["gemm_ms"] else 0,
+                           "attn_tflop": prof["attn_flops"] / 1e12, "attn_ms": prof["attn_ms"],
+                           "attn_TFLOPs": prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] else 0,
+                           "other_kernels_ms": prof["other_ms"], "all_program_ms_eager": prof["all_ms"],
+                           "program_launches": {"%s_B%d_L%d" % k: v for k, v in launch_counts.items()}},
+    }
+
+
 def _pmc_traffic_per_launch():
     """HBM traffic of the GEMM family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE),
     per launch like `achieved`; PMC collection cannot run inside the timed bench itself."""
@@ -187,6 +226,11 @@ def _run():
         frames = len(be.run_transition(fixed_seeds=[420, 421]))
     for k in pipe.stats:
         pipe.stats[k] = 0
+    farm_counts = {}
+    if world > 1 and rank == 0 and not args.no_roofline and args.warmup > 0:
+        # a farmed transition cannot be repeated by rank 0 alone (collectives), so rank 0 counts its own program
+        # launches during the timed transitions (programs exist after the warm-up) and profiles them afterwards
+        install_launch_counters(pipe, farm_counts)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -218,44 +262,23 @@ def _run():
     if rank == 0 and world == 1 and not args.no_roofline:      # (needs a solo transition: no collectives)
         # launches of every (program, batch) per transition: one more transition with counting wrappers
         step_launch_counts = {}
-        for key, prog in pipe._unet_programs.items():
-            orig = prog.prog_step.launch
-
-            def counted(stream=None, _o=orig, _k=key):
-                step_launch_counts[("unet",) + _k] = step_launch_counts.get(("unet",) + _k, 0) + 1
-                return _o(stream)
-            prog.prog_step.launch = counted
-        for key, prog in pipe._vae_programs.items():
-            orig = prog.prog.launch
-
-            def counted_v(stream=None, _o=orig, _k=key):
-                step_launch_counts[("vae",) + _k] = step_launch_counts.get(("vae",) + _k, 0) + 1
-                return _o(stream)
-            prog.prog.launch = counted_v
+        install_launch_counters(pipe, step_launch_counts)
         be.run_transition(fixed_seeds=[420, 421])
         torch.cuda.synchronize()
-        prof = gemm_family_profile(pipe, step_launch_counts)
-        achieved = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] else 0.0
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_f16_kernel<BM,BN,CONV,GEGLU> (all Linear/Conv of UNet+VAE)",
-            "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
-            "traffic": _pmc_traffic_per_launch(),
-            "traffic_unit": "HBM-side bytes per GEMM launch (rocprofv3 PMC passes committed in profiles/; null if absent)",
-            "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
-            "algorithmic_tflop_per_transition_reference": 103.1,
-            "per_transition": {"gemm_tflop": prof["gemm_flops"] / 1e12, "gemm_ms": prof["gemm_ms"],
-                               "gemm_launches": prof["gemm_launches"],
-                               "gemm_avg_us_per_launch": prof["gemm_ms"] * 1e3 / max(prof["gemm_launches"], 1),
-                               "gemm_algorithmic_GBs": prof["gemm_bytes"] / (prof["gemm_ms"] * 1e-3) / 1e9 if prof["gemm_ms"] else 0,
-                               "attn_tflop": prof["attn_flops"] / 1e12, "attn_ms": prof["attn_ms"],
-                               "attn_TFLOPs": prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] else 0,
-                               "other_kernels_ms": prof["other_ms"], "all_program_ms_eager": prof["all_ms"],
-                               "program_launches": {"%s_B%d_L%d" % k: v for k, v in step_launch_counts.items()}},
-        }
+        out["roofline"] = roofline_block(gemm_family_profile(pipe, step_launch_counts), step_launch_counts)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(unet_w, vae_w)
     if world > 1:
         dist.destroy_process_group()
+        if rank == 0 and farm_counts:
+            # rank 0's share of the farmed transition (its UNet / VAE batches), same eager hipEvent replay as N=1
+            try:
+                per_tr = {k: v / max(args.steps, 1) for k, v in farm_counts.items()}
+                out["roofline"] = roofline_block(gemm_family_profile(pipe, per_tr), per_tr)
+                out["roofline"]["scope"] = "rank 0's programs of the farmed transition"
+            except Exception as exc:                      # never lose the throughput line over the profile
+                out["roofline"] = None
+                out["roofline_error"] = repr(exc)
     return out if rank == 0 else None
 
 
