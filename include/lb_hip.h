@@ -104,6 +104,7 @@ int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
 void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5 and split-K */
 void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */
+int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /* the tile (1..5) / split-K / grid lb_gemm_f16 would use; launches nothing */
 void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 

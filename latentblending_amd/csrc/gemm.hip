@@ -376,25 +376,10 @@ static int gemm_launch_impl(LbGemmParams p, int tile, int depth, int variant, in
     return rc;
 }
 
-extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
-    LbGemmParams p = *pp;
+// Tile / split-K policy of one launch (pure host arithmetic; also exported as lb_gemm_plan so that the
+// policy can be pinned by CPU tests and inspected by tools without launching anything).
+static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, long& nblk_out) {
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
-    LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_gemm_f16: empty problem");
-    LB_REQUIRE(p.K % 8 == 0 && p.ldw % 8 == 0, "lb_gemm_f16: K and ldw must be multiples of 8");
-    LB_REQUIRE(p.N % 4 == 0 && (geglu ? p.N % 8 == 0 : true), "lb_gemm_f16: N must be a multiple of 4");
-    LB_REQUIRE(p.ldc % 4 == 0 || (p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: ldc must be a multiple of 4");
-    if (p.conv) {
-        LB_REQUIRE(p.Cin % 8 == 0 && p.ldx % 8 == 0, "lb_gemm_f16: conv Cin/ldx must be multiples of 8");
-        LB_REQUIRE(p.K == p.KH * p.KW * p.Cin, "lb_gemm_f16: conv K != KH*KW*Cin");
-        LB_REQUIRE(p.M % (p.Hout * p.Wout) == 0, "lb_gemm_f16: conv M must be B*Hout*Wout");
-        if (p.scatter)
-            LB_REQUIRE(p.KH == 2 && p.KW == 2 && p.stride == 1 && p.ups == 0 && p.Hout == p.Hin && p.Wout == p.Win &&
-                           !(p.flags & (LB_GEMM_TRANS_OUT | LB_GEMM_GEGLU)) && p.residual == nullptr,
-                       "lb_gemm_f16: sub-pixel conv needs KH=KW=2, stride 1, Hout=Hin, no residual");
-    } else {
-        LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
-    }
-    if (p.alpha == 0.f) p.alpha = 1.f;
     const int n_eff = geglu ? p.N / 2 : p.N;
 
     // tile choice: the largest tile that still gives >= ~1 block per CU; small grids fall back to
@@ -454,6 +439,44 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         if (splitk > k_tiles) splitk = k_tiles;
         if (splitk < 1) splitk = 1;
     }
+    tile_out = tile;
+    splitk_out = splitk;
+    nblk_out = nblk;
+}
+
+extern "C" int lb_gemm_plan(const LbGemmParams* pp, int* tile, int* splitk, long* blocks) {
+    LB_REQUIRE(pp != nullptr && pp->M > 0 && pp->N > 0 && pp->K > 0, "lb_gemm_plan: empty problem");
+    int t = 0, sk = 1;
+    long nb = 0;
+    gemm_plan(*pp, t, sk, nb);
+    if (tile) *tile = t;
+    if (splitk) *splitk = sk;
+    if (blocks) *blocks = nb;
+    return 0;
+}
+
+extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
+    LbGemmParams p = *pp;
+    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
+    LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_gemm_f16: empty problem");
+    LB_REQUIRE(p.K % 8 == 0 && p.ldw % 8 == 0, "lb_gemm_f16: K and ldw must be multiples of 8");
+    LB_REQUIRE(p.N % 4 == 0 && (geglu ? p.N % 8 == 0 : true), "lb_gemm_f16: N must be a multiple of 4");
+    LB_REQUIRE(p.ldc % 4 == 0 || (p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: ldc must be a multiple of 4");
+    if (p.conv) {
+        LB_REQUIRE(p.Cin % 8 == 0 && p.ldx % 8 == 0, "lb_gemm_f16: conv Cin/ldx must be multiples of 8");
+        LB_REQUIRE(p.K == p.KH * p.KW * p.Cin, "lb_gemm_f16: conv K != KH*KW*Cin");
+        LB_REQUIRE(p.M % (p.Hout * p.Wout) == 0, "lb_gemm_f16: conv M must be B*Hout*Wout");
+        if (p.scatter)
+            LB_REQUIRE(p.KH == 2 && p.KW == 2 && p.stride == 1 && p.ups == 0 && p.Hout == p.Hin && p.Wout == p.Win &&
+                           !(p.flags & (LB_GEMM_TRANS_OUT | LB_GEMM_GEGLU)) && p.residual == nullptr,
+                       "lb_gemm_f16: sub-pixel conv needs KH=KW=2, stride 1, Hout=Hin, no residual");
+    } else {
+        LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
+    }
+    if (p.alpha == 0.f) p.alpha = 1.f;
+    int tile = 0, splitk = 1;
+    long nblk = 0;
+    gemm_plan(p, tile, splitk, nblk);
     p.splitk = splitk;
     const int depth = g_depth, variant = g_variant;
     int stages = g_stages;

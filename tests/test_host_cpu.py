@@ -465,3 +465,50 @@ def test_multi_transition_driver_and_movie_json(tmp_path, cpu_backend):
     json.dump([{"foo": 1}], open(bad, "w"))
     with pytest.raises(ValueError):
         replay.load_movie_json(bad)
+
+
+def test_gemm_tile_policy_is_pinned():
+    """lb_gemm_plan (pure host arithmetic of the launcher): the tile / split-K choices the MI355X sweeps led to
+    (profiles/r01_gemm_*.txt, tools/ab_policy.py) for the shapes the SDXL programs launch.  Tiles: 1 = 128x128,
+    2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves)."""
+    from latentblending_amd.hip import lib
+
+    def plan(M, N, K, conv=False, geglu=False, ws=None, zero_page=True):
+        if ws is None:                  # the emitter's rule (native/runtime.py _gemm_ws): slabs only for <= 640 64x64 tiles
+            ws = ((M + 63) // 64) * ((N + 63) // 64) <= 640
+        p = lib.LbGemmParams()
+        p.M, p.N, p.K, p.conv = M, N, K, int(conv)
+        p.flags = lib.GEMM_GEGLU if geglu else 0
+        p.partial = 64 if ws else None                # (never dereferenced by the planner)
+        p.zero_page = 64 if zero_page else None
+        t, sk, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+        lib.api.lb_gemm_plan(ctypes.byref(p), ctypes.byref(t), ctypes.byref(sk), ctypes.byref(nb))
+        return t.value, sk.value, nb.value
+
+    # UNet at B=17 (M = 17*256 / 17*1024)
+    assert plan(4352, 10240, 1280, geglu=True)[:2] == (5, 1)            # GEGLU: 256x256, 680 blocks
+    assert plan(4352, 10240, 1280, geglu=True)[2] == 17 * 40
+    assert plan(4352, 1280, 1280)[:2] == (4, 1)                         # 170 blocks of 256x128
+    assert plan(4352, 1280, 5120)[:2] == (4, 1)
+    assert plan(4352, 2560, 1280)[:2] == (5, 1)                         # one round of 256x256 beats two of 256x128
+    assert plan(17408, 640, 640)[0] in (1, 2)                           # short K: 4-wave tiles
+    assert plan(17408, 640, 5760, conv=True)[0] == 5
+    assert plan(69632, 320, 2880, conv=True)[0] == 1                    # N = 320 pads badly to 256-wide tiles
+    # VAE at B=17
+    assert plan(4456448, 128, 1152, conv=True)[0] == 4                  # N = 128: 256x128
+    assert plan(1114112, 256, 2304, conv=True)[0] == 5
+    assert plan(4456448, 4, 1152, conv=True)[0] == 3                    # conv_out: 3 real columns
+    # UNet at B=2 (M = 512 / 2048): small tiles, split-K where K is long
+    assert plan(512, 1280, 1280) == (3, 1, 160)
+    assert plan(512, 1280, 5120) == (3, 4, 160)
+    assert plan(512, 1280, 11520, conv=True) == (3, 4, 160)
+    assert plan(2048, 640, 5760, conv=True) == (2, 4, 160)              # 128x64 + split instead of 320 unsplittable blocks
+    assert plan(2048, 640, 640) == (3, 1, 320)
+    assert plan(512, 1280, 5120, ws=False)[1] == 1                      # no slab workspace -> never splits
+    # without the zero page the direct-to-LDS family (and its 8-wave tiles) is not available
+    assert plan(4352, 10240, 1280, geglu=True, zero_page=False)[0] == 1
+    lib.api.lb_gemm_set_policy(2)                                       # A/B switch: no 256x256
+    try:
+        assert plan(4352, 10240, 1280, geglu=True)[0] == 4
+    finally:
+        lib.api.lb_gemm_set_policy(0)
