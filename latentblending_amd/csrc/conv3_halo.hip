@@ -1,0 +1,258 @@
+// 3x3 / stride 1 / pad 1 convolution from an LDS-resident HALO tile (gfx950).  EXPERIMENTAL in round 1:
+// compiled into liblbhip.so and reachable through lb_conv3x3_halo_f16 / lb_gemm_set_experimental(1), but
+// not on the default path and not yet validated on hardware (written after the round's GPU budget was
+// spent; tests/test_kernels_gpu.py::test_conv3x3_halo_* are skipped unless LB_TEST_EXPERIMENTAL=1).
+//
+// Why: the implicit-GEMM conv (gemm_glds.hip) stages every input pixel once per tap - 9 times - and the
+// ablation (profiles/r01_gemm_ablation.txt) shows the kernel family bound by exactly that global->LDS
+// stream.  Staged operand bytes per MFLOP: 256x128 tile 11.4 KB, 256x256 tile 7.6 KB.  Here a block owns
+// a 2-D tile of TH x TW = 256 output pixels; per 64-channel chunk of Cin it stages the (TH+2) x (TW+2)
+// halo ONCE (43.5 KB) and all 9 taps read it through shifted LDS rows; only the weight tiles (16 KB per
+// tap and chunk) stream per step:  5.05 KB / MFLOP.  The loader knows every halo pixel's (y, x), so
+// out-of-image pixels are fetched from the zero page and the fragment reads need no masks.
+//
+// Block: 512 threads = 8 waves (4 along M x 2 along N), wave tile 64 pixels x 64 channels, MFMA
+// 16x16x32 f16 with the same operand / LDS conventions as gemm_glds.hip ([rows][64] fp16, 16-B chunks
+// XOR-swizzled by (row & 7), swizzle applied to the global source address of the direct-to-LDS loads).
+// Local pixel m = wave_m*64 + 16 i + l16  ->  (py, px) = (m / TW, m % TW): the 16 lanes of an MFMA row
+// group are 16 consecutive pixels of one image row (conflict-free LDS rows, contiguous NHWC stores).
+//
+// LDS (150 KiB): two halo buffers of HRP = 8*ceil((TH+2)(TW+2)/8) rows (chunk c in buffer c & 1) and a
+// 4-slot ring of weight tiles (BN rows).  One STEP = one (chunk c, tap) pair: 32 MFMAs per wave.
+//   * W(t) is requested 3 steps ahead (slot t & 3 was consumed by step t-4... t-1 before the barrier),
+//   * the halo of chunk c+1 is requested during taps 0..5 of chunk c (<= 1 load per thread and step),
+//   * per step every thread issues [halo load if any] then 2 weight loads, interleaved with the MFMAs.
+// Wait before step t (then ONE s_barrier): everything except the loads of steps t-1 and t-2 must have
+// landed => s_waitcnt vmcnt(cnt(tap-1) + cnt(tap-2)), cnt(tap) = 2 + [tap <= 4]; the 6th halo load exists
+// only in waves 0..(HRG-41) (tap 5) and is simply counted as absent: a wave that has it waits for one
+// more (older) load, never for fewer.  Past-the-end requests (last chunk's "next halo", the last three
+// steps' weight tiles) are still issued, masked to the zero page, so the constants hold to the end.
+#include <type_traits>
+#include "lb_common.h"
+#include "lb_gemm.h"
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void halo_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BN, int TW>
+__global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p) {
+    constexpr int TH = 256 / TW;
+    constexpr int HWP = TW + 2;                         // halo width in pixels
+    constexpr int HR = (TH + 2) * HWP;                  // halo pixels (LDS rows in use)
+    constexpr int HRG = (HR + 7) / 8;                   // 8-row groups = wave instructions per halo
+    constexpr int HRP = HRG * 8;                        // rows per halo buffer
+    constexpr int EXTRA = HRG - 40;                     // groups left after 5 rounds of 8 waves (1..3)
+    constexpr int WI = BN * 8 / 512;                    // weight loads per thread and step (2)
+    constexpr int TM = 4, TN = BN / 32;                 // 16x16 tiles per wave (64 pixels x BN/2 channels)
+    static_assert(EXTRA >= 1 && EXTRA <= 8, "halo row groups must fit 6 rounds of 8 waves");
+    static_assert(WI == 2, "the vmcnt schedule assumes two weight loads per thread and step");
+    extern __shared__ __attribute__((aligned(16))) f16 lds[];
+    f16* const halo0 = lds;
+    f16* const wring = lds + 2 * HRP * 64;              // 4 slots of BN rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int g = lane >> 4, l16 = lane & 15;
+
+    // ---- block -> (image b, tile ty, tx, channel block) ; XCD-contiguous, channel block fastest ----
+    const int n_blocks = (p.N + BN - 1) / BN;
+    const int tiles_x = p.Win / TW, tiles_y = p.Hin / TH;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int block_n = bid % n_blocks;
+    int tile = bid / n_blocks;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    const int ty = tile % tiles_y;
+    const int b = tile / tiles_y;
+    const int n0 = block_n * BN;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int nchunks = p.Cin / 64;
+    const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
+
+    // ---- loader state -------------------------------------------------------------------------------
+    // halo: wave instruction j (0..5) covers row group gidx(j); lane (r8 = lane>>3, slot = lane&7) fetches
+    // logical chunk slot ^ r8 of halo row gidx*8 + r8
+    const int r8 = lane >> 3;
+    const int cl = (lane & 7) ^ r8;
+    long h_off[6];                                      // element offset of the pixel (chunk 0), -1 = zero page
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int gidx = j < 5 ? j * 8 + wave : 40 + wave;
+        const int row = gidx * 8 + r8;
+        const int hy = row / HWP, hx = row - hy * HWP;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        const bool ok = (j < 5 || wave < EXTRA) && row < HR && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        h_off[j] = ok ? ((long)(b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 : -1;
+    }
+    // weights: thread stages rows (tid>>3) + 64 i of the BN x 64 tile
+    long w_off[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int n = n0 + (tid >> 3) + i * 64;
+        w_off[i] = n < p.N ? (long)n * p.ldw + cl * 8 : -1;
+    }
+
+    auto issue_halo = [&](int j, int chunk) {           // one wave instruction of the halo of `chunk`
+        const bool live = h_off[j] >= 0 && chunk < nchunks;
+        const lb_half* src = live ? p.A + h_off[j] + (long)chunk * 64 : zero;
+        const int gidx = j < 5 ? j * 8 + wave : 40 + wave;
+        f16* dst = halo0 + (chunk & 1) * (HRP * 64) + gidx * 8 * 64;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+    auto issue_weight = [&](int i, int chunk, int tap, int slot) {
+        const bool live = w_off[i] >= 0 && chunk < nchunks;
+        const lb_half* src = live ? p.W + w_off[i] + (long)tap * p.Cin + (long)chunk * 64 : zero;
+        f16* dst = wring + slot * (BN * 64) + (wave * 8 + i * 64) * 64;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+
+    // ---- consumer state -----------------------------------------------------------------------------
+    int hbase[TM];                                      // halo row of tap (0, 0) of the lane's pixel i
+    int mrow[TM];                                       // global output pixel index
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = wave_m * 64 + i * 16 + l16;
+        const int py = m / TW, px = m - py * TW;
+        hbase[i] = py * HWP + px;
+        mrow[i] = (b * p.Hin + y0 + py) * p.Win + x0 + px;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto read_frags = [&](const f16* hb, const f16* wb, int shift, int s, f16x8 (&af)[TM], f16x8 (&wf)[TN]) {
+        const int chunk = s * 4 + g;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = hbase[i] + shift;
+            af[i] = *reinterpret_cast<const f16x8*>(hb + r * 64 + ((chunk ^ (r & 7)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = j * 16 + l16;
+            wf[j] = *reinterpret_cast<const f16x8*>(wb + (wave_n * (BN / 2) + r) * 64 + ((chunk ^ (r & 7)) << 3));
+        }
+    };
+    auto mma_rows = [&](const f16x8 (&af)[TM], const f16x8 (&wf)[TN], int i_lo, int i_hi) {
+#pragma unroll
+        for (int i = i_lo; i < i_hi; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: halo of chunk 0, weight tiles of steps 0..2 ----------------------------------------
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if (j < 5 || wave < EXTRA) issue_halo(j, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < WI; ++i) issue_weight(i, 0, t, t);
+
+    // one step; TAP is a compile-time constant so that every count below is an immediate
+    auto step = [&](auto tap_c, int c) {
+        constexpr int TAP = decltype(tap_c)::value;
+        constexpr int P1 = (TAP + 8) % 9, P2 = (TAP + 7) % 9;          // taps of the two previous steps
+        constexpr int CNT = (2 + (P1 <= 4 ? 1 : 0)) + (2 + (P2 <= 4 ? 1 : 0));
+        halo_wait_barrier<CNT>();
+        const int slot = (c + TAP) & 3;                  // (9 c + TAP) mod 4
+        const f16* hb = halo0 + (c & 1) * (HRP * 64);
+        const f16* wb = wring + slot * (BN * 64);
+        constexpr int KY = TAP / 3, KX = TAP % 3;
+        // the tap's row shift goes through an opaque register: the 72 swizzled fragment addresses of the nine
+        // taps are loop-invariant, and hoisting them out of the chunk loop costs more registers than the file has
+        int shift = KY * HWP + KX;
+        asm volatile("" : "+v"(shift));
+        // requests of this step: halo part of chunk c+1 (taps 0..5), then W(step + 3)
+        constexpr int TAP3 = (TAP + 3) % 9;
+        const int c3 = c + (TAP + 3) / 9;
+        const int slot3 = (slot + 3) & 3;
+        f16x8 a0[TM], w0[TN], a1[TM], w1[TN];
+        read_frags(hb, wb, shift, 0, a0, w0);
+        if (TAP <= 4) issue_halo(TAP, c + 1);
+        else if (TAP == 5) { if (wave < EXTRA) issue_halo(5, c + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rows(a0, w0, 0, TM / 2);
+        read_frags(hb, wb, shift, 1, a1, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_weight(0, c3, TAP3, slot3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rows(a0, w0, TM / 2, TM);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_weight(1, c3, TAP3, slot3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rows(a1, w1, 0, TM);
+    };
+
+    for (int c = 0; c < nchunks; ++c) {
+        step(std::integral_constant<int, 0>{}, c);
+        step(std::integral_constant<int, 1>{}, c);
+        step(std::integral_constant<int, 2>{}, c);
+        step(std::integral_constant<int, 3>{}, c);
+        step(std::integral_constant<int, 4>{}, c);
+        step(std::integral_constant<int, 5>{}, c);
+        step(std::integral_constant<int, 6>{}, c);
+        step(std::integral_constant<int, 7>{}, c);
+        step(std::integral_constant<int, 8>{}, c);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the masked tail requests before the epilogue
+
+    lb_gemm_tile_epilogue_rows<TM, TN, false>(p, acc, [&](int i) { return mrow[i]; },
+                                              n0 + wave_n * (BN / 2) + 4 * g, 0);
+}
+
+template <int BN, int TW>
+static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
+    constexpr int TH = 256 / TW;
+    constexpr int HRP = (((TH + 2) * (TW + 2) + 7) / 8) * 8;
+    constexpr int SMEM = (2 * HRP * 64 + 4 * BN * 64) * (int)sizeof(f16);
+    static bool allowed = false;
+    if (!allowed) {                                     // (first call happens at record time, outside any capture)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        allowed = true;
+    }
+    const long tiles = (long)(p.M / (p.Hin * p.Win)) * (p.Hin / TH) * (p.Win / TW);
+    const long nblk = tiles * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW>), dim3((unsigned)nblk), dim3(512), SMEM, stream, p);
+    return lb_check_launch("lb_conv3x3_halo_f16");
+}
+
+// 0 = not eligible, else the tile width the halo kernel would use
+int lb_conv3x3_halo_eligible(const LbGemmParams& p) {
+    if (!p.conv || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.ups || p.scatter) return 0;
+    if (p.Hout != p.Hin || p.Wout != p.Win || p.Cin % 64 != 0 || p.K != 9 * p.Cin) return 0;
+    if (p.zero_page == nullptr || (p.flags & LB_GEMM_GEGLU) || p.N % 4 != 0) return 0;
+    if (p.M % (p.Hin * p.Win) != 0) return 0;
+    if (p.Win % 32 == 0 && p.Hin % 8 == 0) return 32;
+    if (p.Win % 16 == 0 && p.Hin % 16 == 0) return 16;
+    return 0;
+}
+
+int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream) {
+    if (p.alpha == 0.f) p.alpha = 1.f;
+    p.splitk = 1;
+    return lb_conv3x3_halo_eligible(p) == 32 ? launch_halo<128, 32>(p, stream) : launch_halo<128, 16>(p, stream);
+}
+
+extern "C" int lb_conv3x3_halo_f16(const LbGemmParams* pp, void* stream) {
+    LbGemmParams p = *pp;
+    LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_conv3x3_halo_f16: empty problem");
+    LB_REQUIRE(lb_conv3x3_halo_eligible(p) != 0,
+               "lb_conv3x3_halo_f16: needs a 3x3 / stride 1 / pad 1 conv, Cin % 64 == 0, W % 16 == 0, zero page");
+    LB_REQUIRE(p.ldw % 8 == 0 && p.ldx % 8 == 0 && (p.ldc % 4 == 0 || (p.flags & LB_GEMM_TRANS_OUT)),
+               "lb_conv3x3_halo_f16: ldw / ldx multiples of 8, ldc multiple of 4");
+    LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
+}

@@ -321,6 +321,12 @@ extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 // 256x256 for convolutions, bit 3 no 256x256 for plain/GEGLU, bit 4 no 256x128 for convolutions
 static int g_policy_off = 0;
 extern "C" void lb_gemm_set_policy(int disable_mask) { g_policy_off = disable_mask; }
+// Opt-in code paths that are not (yet) on the default route.  bit 0: eligible 3x3 convs go to the halo kernel
+// (conv3_halo.hip; unvalidated at the end of round 1).
+int lb_conv3x3_halo_eligible(const LbGemmParams& p);
+int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream);
+static int g_experimental = 0;
+extern "C" void lb_gemm_set_experimental(int flags) { g_experimental = flags; }
 
 // direct-to-LDS variant (gemm_glds.hip)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream);
@@ -474,6 +480,8 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
     }
     if (p.alpha == 0.f) p.alpha = 1.f;
+    if ((g_experimental & 1) && !g_force_tile && lb_conv3x3_halo_eligible(p) && (long)p.M * p.N >= (1L << 22))
+        LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
     int tile = 0, splitk = 1;
     long nblk = 0;
     gemm_plan(p, tile, splitk, nblk);

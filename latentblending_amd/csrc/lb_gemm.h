@@ -79,9 +79,11 @@ __device__ __forceinline__ void lb_gemm_write4(const LbGemmParams& p, long crow,
     }
 }
 
-template <int TM, int TN, bool GEGLU>
-__device__ __forceinline__ void lb_gemm_tile_epilogue(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
-                                                      int row0, int col0, int gcol0) {
+// RowFn: i -> global output row of the lane's i-th 16-row group (row0 + 16 i for the GEMM kernels; the pixel
+// index of a 2-D spatial tile for the halo conv kernel).
+template <int TM, int TN, bool GEGLU, typename RowFn>
+__device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
+                                                           RowFn row_of, int col0, int gcol0) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (GEGLU) {
         constexpr int TP = TN / 2 > 0 ? TN / 2 : 1;
@@ -96,7 +98,7 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue(const LbGemmParams& p, con
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = row0 + i * 16;
+            const int m = row_of(i);
             if (m >= p.M) continue;
 #pragma unroll
             for (int jp = 0; jp < TP; ++jp) {
@@ -116,7 +118,7 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue(const LbGemmParams& p, con
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = row0 + i * 16;
+        const int m = row_of(i);
         const bool m_ok = m < p.M;
         const int mc = m_ok ? m : p.M - 1;
         f32x4 add[TN];                  // bias + row vector + residual of this row's TN column groups
@@ -179,4 +181,10 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue(const LbGemmParams& p, con
             lb_gemm_write4(p, crow, m, n, o);
         }
     }
+}
+
+template <int TM, int TN, bool GEGLU>
+__device__ __forceinline__ void lb_gemm_tile_epilogue(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
+                                                      int row0, int col0, int gcol0) {
+    lb_gemm_tile_epilogue_rows<TM, TN, GEGLU>(p, acc, [row0](int i) { return row0 + i * 16; }, col0, gcol0);
 }

@@ -188,7 +188,10 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     if splitk_ws and not (flags & lib.GEMM_GEGLU):
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)
         p.partial = ws.data_ptr()
-    api.lb_gemm_f16(C.byref(p), stream_ptr())
+    if conv is not None and conv.get("halo"):         # experimental halo-tile 3x3 kernel (csrc/conv3_halo.hip)
+        api.lb_conv3x3_halo_f16(C.byref(p), stream_ptr())
+    else:
+        api.lb_gemm_f16(C.byref(p), stream_ptr())
     return out
 
 

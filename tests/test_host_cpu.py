@@ -512,3 +512,60 @@ def test_gemm_tile_policy_is_pinned():
         assert plan(4352, 10240, 1280, geglu=True)[0] == 4
     finally:
         lib.api.lb_gemm_set_policy(0)
+
+
+@pytest.mark.parametrize("TW,H,W", [(32, 16, 64), (16, 16, 16), (32, 8, 32)])
+def test_halo_conv_index_math(TW, H, W):
+    """Row-level emulation of csrc/conv3_halo.hip's address arithmetic (the kernel itself could not be run
+    before the round's GPU budget ended): the loader's (wave, instruction, lane) -> halo row -> pixel mapping
+    covers the halo exactly once, zero-fills out-of-image pixels, and `hbase + ky*(TW+2) + kx` reads the input
+    pixel each tap needs; the result at `mrow` equals conv2d."""
+    import torch.nn.functional as F
+    TH, HWP = 256 // TW, TW + 2
+    HR = (TH + 2) * HWP
+    HRG = (HR + 7) // 8
+    EXTRA = HRG - 40
+    assert 1 <= EXTRA <= 8
+    B, Cin, N = 2, 64, 8
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, Cin, generator=g, dtype=torch.float64)
+    wt = torch.randn(N, 3, 3, Cin, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, N)
+    out = torch.full((B * H * W, N), float("nan"), dtype=torch.float64)
+    tiles_x, tiles_y = W // TW, H // TH
+    for tile in range(B * tiles_y * tiles_x):
+        tx, rest = tile % tiles_x, tile // tiles_x
+        ty, b = rest % tiles_y, rest // tiles_y
+        y0, x0 = ty * TH, tx * TW
+        halo = torch.full((HRG * 8, Cin), float("nan"), dtype=torch.float64)
+        written = np.zeros(HRG * 8, dtype=int)
+        for wave in range(8):
+            for j in range(6):
+                if not (j < 5 or wave < EXTRA):
+                    continue                              # (the kernel does not issue this instruction)
+                gidx = j * 8 + wave if j < 5 else 40 + wave
+                for r8 in range(8):
+                    row = gidx * 8 + r8
+                    hy, hx = divmod(row, HWP)
+                    y, xx = y0 + hy - 1, x0 + hx - 1
+                    ok = row < HR and 0 <= y < H and 0 <= xx < W
+                    halo[row] = x[b, y, xx] if ok else 0.0
+                    written[row] += 1
+        assert (written[:HR] == 1).all() and written.max() == 1
+        for wave_m in range(4):
+            for i in range(4):
+                for l16 in range(16):
+                    m = wave_m * 64 + i * 16 + l16
+                    py, px = divmod(m, TW)
+                    hbase = py * HWP + px
+                    mrow = (b * H + y0 + py) * W + x0 + px
+                    acc = torch.zeros(N, dtype=torch.float64)
+                    for tap in range(9):
+                        ky, kx = divmod(tap, 3)
+                        acc += wt[:, ky, kx] @ halo[hbase + ky * HWP + kx]
+                    assert torch.isnan(out[mrow]).all()
+                    out[mrow] = acc
+    assert torch.allclose(out, ref, rtol=1e-12, atol=1e-12)
+    # request accounting of one step: [halo?] + 2 weight loads; wait constant = loads of the two previous steps
+    cnt = lambda tap: 2 + (1 if tap % 9 <= 4 else 0)
+    assert [cnt(t - 1) + cnt(t - 2) for t in range(9)] == [4, 5, 6, 6, 6, 6, 5, 4, 4]

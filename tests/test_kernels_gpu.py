@@ -6,6 +6,7 @@ exact); fp16 GEMM / conv / attention / norms: rel-L2 <= 2e-3 and max-abs <= 2^-8
 (+ small absolute floor) against an fp32 reference evaluated on the same fp16-rounded inputs.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -494,3 +495,34 @@ def test_subpixel_upsample_conv(variant, results_log):
     finally:
         l.api.lb_gemm_set_variant(1, 0)
     check_close(results_log, f"subpixel_upconv_v{variant}", out, ref, rel=3e-3)
+
+
+# ------------------------------------------------------------------ experimental: halo-tile 3x3 conv
+EXPERIMENTAL = os.environ.get("LB_TEST_EXPERIMENTAL") == "1"
+
+
+@pytest.mark.skipif(not EXPERIMENTAL, reason="csrc/conv3_halo.hip is not validated yet (set LB_TEST_EXPERIMENTAL=1)")
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 128), (1, 64, 64, 128, 320), (3, 16, 16, 192, 132), (1, 8, 96, 64, 64),
+                                  (2, 48, 16, 128, 256)])
+def test_conv3x3_halo_against_conv2d(case, results_log):
+    """3x3 / stride 1 / pad 1 conv from the LDS-resident halo tile vs F.conv2d, incl. bias + residual, ragged N,
+    TW = 32 and TW = 16 tilings, multi-chunk Cin, image borders on every side of a tile."""
+    o, l = ops(), lib()
+    B, H, Wd, Cin, Cout = case
+    x = rnd(B, Cin, H, Wd, seed=90)
+    w = rnd(Cout, Cin, 3, 3, seed=91, scale=(Cin * 9) ** -0.5)
+    b = rnd(Cout, seed=92, dtype=torch.float32)
+    res = rnd(B, H, Wd, Cout, seed=93)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1) + res.float()
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    wp = o.pack_conv_weight(w, Cin)
+    got = o.gemm(xn.to(DEV), wp.to(DEV), bias=b.to(DEV), residual=res.to(DEV),
+                 conv=dict(KH=3, KW=3, stride=1, pad=1, halo=True))
+    check_close(results_log, f"halo_conv_{'_'.join(map(str, case))}", got, ref)
+    # and through the lb_gemm_f16 router
+    l.api.lb_gemm_set_experimental(1)
+    try:
+        got2 = o.gemm(xn.to(DEV), wp.to(DEV), bias=b.to(DEV), residual=res.to(DEV), conv=dict(KH=3, KW=3, stride=1, pad=1))
+    finally:
+        l.api.lb_gemm_set_experimental(0)
+    check_close(results_log, f"halo_conv_routed_{'_'.join(map(str, case))}", got2, ref)
