@@ -11,10 +11,12 @@ from latentblending_amd.hip import lib
 from latentblending_amd.native.runtime import Program
 
 DEV, REP = "cuda", 20
+HALO = "--halo" in sys.argv         # also time the experimental halo-tile 3x3 kernel on the conv shapes
 BIG_ONLY = "--big" in sys.argv      # only the big-M shapes, direct-to-LDS variants (256x128 tile study)
 
 
-def time_variant(p, tile, depth, splitk, glds_stages=0):
+def time_variant(p, tile, depth, splitk, glds_stages=0, halo=False):
+    lib.api.lb_gemm_set_experimental(1 if halo else 0)     # 3x3 convs through csrc/conv3_halo.hip (opt-in)
     lib.api.lb_gemm_set_tuning(tile, splitk)
     lib.api.lb_gemm_set_depth(depth)
     if tile == 0 and depth == 0 and not glds_stages:
@@ -30,6 +32,7 @@ def time_variant(p, tile, depth, splitk, glds_stages=0):
         lib.api.lb_gemm_set_tuning(0, 0)
         lib.api.lb_gemm_set_depth(0)
         lib.api.lb_gemm_set_variant(-1, 0)
+        lib.api.lb_gemm_set_experimental(0)
     prog.instantiate()
     st = torch.cuda.current_stream().cuda_stream
     prog.launch(st)
@@ -104,6 +107,10 @@ def main():
         lib.api.lb_gemm_set_depth(0)
         p.partial = ws.data_ptr() if small and sh[0] != "geglu" else None
         auto = time_variant(p, 0, 0, 0)
+        if HALO and sh[0] == "conv":
+            row["variants"]["halo"] = time_variant(p, 0, 0, 0, halo=True)
+            if row["variants"]["halo"] < best[1]:
+                best = ("halo", row["variants"]["halo"])
         row.update(best=best[0], best_us=best[1], best_TF=flops / best[1] / 1e6, auto_us=auto, auto_TF=flops / auto / 1e6)
         results.append(row)
         top = sorted(row["variants"].items(), key=lambda kv: kv[1])[:4]
