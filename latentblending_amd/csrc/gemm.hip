@@ -321,12 +321,19 @@ extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 // 256x256 for convolutions, bit 3 no 256x256 for plain/GEGLU, bit 4 no 256x128 for convolutions
 static int g_policy_off = 0;
 extern "C" void lb_gemm_set_policy(int disable_mask) { g_policy_off = disable_mask; }
-// Opt-in code paths that are not (yet) on the default route.  bit 0: eligible 3x3 convs go to the halo kernel
-// (conv3_halo.hip; unvalidated at the end of round 1).
+// 3x3 / stride 1 / pad 1 convs from an LDS-resident halo tile (conv3_halo.hip): 1.27-1.79x the implicit GEMM on
+// every conv of the benchmark's B=17 programs (profiles/r02_halo_bench.txt).  mode 0 = never, 1 = whenever the
+// halo grid has at least LB_HALO_MIN_BLOCKS blocks (default), 2 = whenever eligible (tests / A-B studies).
 int lb_conv3x3_halo_eligible(const LbGemmParams& p);
+long lb_conv3x3_halo_blocks(const LbGemmParams& p);
 int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream);
-static int g_experimental = 0;
-extern "C" void lb_gemm_set_experimental(int flags) { g_experimental = flags; }
+#define LB_HALO_MIN_BLOCKS 96
+static int g_halo = 1;
+extern "C" void lb_gemm_set_halo(int mode) { g_halo = mode; }
+static bool use_halo(const LbGemmParams& p) {
+    if (g_halo == 0 || g_force_tile || !lb_conv3x3_halo_eligible(p)) return false;
+    return g_halo == 2 || lb_conv3x3_halo_blocks(p) >= LB_HALO_MIN_BLOCKS;
+}
 
 // direct-to-LDS variant (gemm_glds.hip)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream);
@@ -454,7 +461,8 @@ extern "C" int lb_gemm_plan(const LbGemmParams* pp, int* tile, int* splitk, long
     LB_REQUIRE(pp != nullptr && pp->M > 0 && pp->N > 0 && pp->K > 0, "lb_gemm_plan: empty problem");
     int t = 0, sk = 1;
     long nb = 0;
-    gemm_plan(*pp, t, sk, nb);
+    if (use_halo(*pp)) { t = 6; nb = lb_conv3x3_halo_blocks(*pp); }     // tile code 6 = halo-tile conv kernel
+    else gemm_plan(*pp, t, sk, nb);
     if (tile) *tile = t;
     if (splitk) *splitk = sk;
     if (blocks) *blocks = nb;
@@ -480,8 +488,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
     }
     if (p.alpha == 0.f) p.alpha = 1.f;
-    if ((g_experimental & 1) && !g_force_tile && lb_conv3x3_halo_eligible(p) && (long)p.M * p.N >= (1L << 22))
-        LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
+    if (use_halo(p)) LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
     int tile = 0, splitk = 1;
     long nblk = 0;
     gemm_plan(p, tile, splitk, nblk);

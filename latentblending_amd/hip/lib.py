@@ -67,7 +67,7 @@ SIGNATURES = {
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
     "lb_gemm_set_policy": (None, [_i]),
-    "lb_gemm_set_experimental": (None, [_i]),
+    "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_gemm_plan": (_i, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
@@ -101,7 +101,7 @@ SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_experimental", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

@@ -99,18 +99,20 @@ class StableDiffusionXLPipeline:
     def __init__(self, turbo: bool = True, unet_cfg: Optional[UNetConfig] = None,
                  vae_cfg: Optional[VAEConfig] = None, unet_provider=None, vae_provider=None,
                  lpips_provider=None, device="cuda", seed: int = 0, name_or_path: Optional[str] = None,
-                 text_encoder_fn=None):
+                 text_encoder_fn=None, unet_native: Optional[NativeUNet] = None,
+                 vae_native: Optional[NativeVAEDecoder] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("NativeSDXLPipe needs an MI355X (HIP device); there is no CPU fallback")
         self.device = torch.device(device)
         self._execution_device = self.device
-        self.unet_cfg = unet_cfg or UNetConfig(sample_size=64 if turbo else 128)
-        self.vae_cfg = vae_cfg or VAEConfig()
+        # (already packed modules may be shared between pipes: 5.5 GB of UNet weights need not be packed twice)
+        self.unet_cfg = unet_native.cfg if unet_native is not None else (unet_cfg or UNetConfig(sample_size=64 if turbo else 128))
+        self.vae_cfg = vae_native.cfg if vae_native is not None else (vae_cfg or VAEConfig())
         self._name_or_path = name_or_path or ("stabilityai/sdxl-turbo" if turbo else
                                               "stabilityai/stable-diffusion-xl-base-1.0")
         self.dtype = F16
-        self.unet_native = NativeUNet(self.unet_cfg, unet_provider or SyntheticProvider(seed), self.device)
-        self.vae_native = NativeVAEDecoder(self.vae_cfg, vae_provider or SyntheticProvider(seed + 1), self.device)
+        self.unet_native = unet_native or NativeUNet(self.unet_cfg, unet_provider or SyntheticProvider(seed), self.device)
+        self.vae_native = vae_native or NativeVAEDecoder(self.vae_cfg, vae_provider or SyntheticProvider(seed + 1), self.device)
         self.lpips_metric = NativeLPIPS(lpips_provider or SyntheticProvider(7), self.device)
         self.scheduler = NativeEulerScheduler(ancestral=turbo, device=self.device)
         self.unet = _UNetFacade(self)

@@ -497,11 +497,7 @@ def test_subpixel_upsample_conv(variant, results_log):
     check_close(results_log, f"subpixel_upconv_v{variant}", out, ref, rel=3e-3)
 
 
-# ------------------------------------------------------------------ experimental: halo-tile 3x3 conv
-EXPERIMENTAL = os.environ.get("LB_TEST_EXPERIMENTAL") == "1"
-
-
-@pytest.mark.skipif(not EXPERIMENTAL, reason="csrc/conv3_halo.hip is not validated yet (set LB_TEST_EXPERIMENTAL=1)")
+# ------------------------------------------------------------------ halo-tile 3x3 conv
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 128), (1, 64, 64, 128, 320), (3, 16, 16, 192, 132), (1, 8, 96, 64, 64),
                                   (2, 48, 16, 128, 256)])
 def test_conv3x3_halo_against_conv2d(case, results_log):
@@ -520,9 +516,9 @@ def test_conv3x3_halo_against_conv2d(case, results_log):
                  conv=dict(KH=3, KW=3, stride=1, pad=1, halo=True))
     check_close(results_log, f"halo_conv_{'_'.join(map(str, case))}", got, ref)
     # and through the lb_gemm_f16 router
-    l.api.lb_gemm_set_experimental(1)
+    l.api.lb_gemm_set_halo(2)
     try:
         got2 = o.gemm(xn.to(DEV), wp.to(DEV), bias=b.to(DEV), residual=res.to(DEV), conv=dict(KH=3, KW=3, stride=1, pad=1))
     finally:
-        l.api.lb_gemm_set_experimental(0)
+        l.api.lb_gemm_set_halo(1)
     check_close(results_log, f"halo_conv_routed_{'_'.join(map(str, case))}", got2, ref)

@@ -16,7 +16,7 @@ BIG_ONLY = "--big" in sys.argv      # only the big-M shapes, direct-to-LDS varia
 
 
 def time_variant(p, tile, depth, splitk, glds_stages=0, halo=False):
-    lib.api.lb_gemm_set_experimental(1 if halo else 0)     # 3x3 convs through csrc/conv3_halo.hip (opt-in)
+    lib.api.lb_gemm_set_halo(2 if halo else 0)     # 3x3 convs through csrc/conv3_halo.hip, or never
     lib.api.lb_gemm_set_tuning(tile, splitk)
     lib.api.lb_gemm_set_depth(depth)
     if tile == 0 and depth == 0 and not glds_stages:
@@ -32,7 +32,7 @@ def time_variant(p, tile, depth, splitk, glds_stages=0, halo=False):
         lib.api.lb_gemm_set_tuning(0, 0)
         lib.api.lb_gemm_set_depth(0)
         lib.api.lb_gemm_set_variant(-1, 0)
-        lib.api.lb_gemm_set_experimental(0)
+        lib.api.lb_gemm_set_halo(1)
     prog.instantiate()
     st = torch.cuda.current_stream().cuda_stream
     prog.launch(st)
