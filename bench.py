@@ -202,7 +202,8 @@ def _run():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     t0 = time.perf_counter()
     unet_prov, vae_prov = N.SyntheticProvider(0, keep=want_cpu), N.SyntheticProvider(1, keep=want_cpu)
-    pipe = N.NativeSDXLPipe(turbo=True, unet_provider=unet_prov, vae_provider=vae_prov, device=f"cuda:{local_rank}")
+    pipe = N.NativeSDXLPipe(turbo=True, unet_provider=unet_prov, vae_provider=vae_prov, device=f"cuda:{local_rank}",
+                            allow_synthetic=True)      # ("data": "synthetic" in the JSON line)
     t_weights = time.perf_counter() - t0
     unet_w, vae_w = unet_prov.state, vae_prov.state
     farm = None

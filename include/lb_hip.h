@@ -130,13 +130,16 @@ int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* be
 typedef struct LbAttnParams {
     const lb_half* Q;    /* element (b, q, h, d) at Q[(b*Sq + q)*ldq + h*64 + d] */
     const lb_half* K;    /* element (b, k, h, d) at K[(b*Skv + k)*ldk + h*64 + d] */
-    const lb_half* Vt;   /* element (h, d, b, k) at Vt[(h*64 + d)*ldvt + b*Skv + k]  (V transposed) */
+    const lb_half* V;    /* element (b, k, h, d) at V[(b*Skv + k)*ldv + h*64 + d]  (token-major, like K) */
     lb_half* O;          /* like Q with ldo */
-    int B, H, Sq, Skv, Skv_valid;   /* keys >= Skv_valid are masked; Skv % 8 == 0 */
-    int ldq, ldk, ldvt, ldo;
+    int B, H, Sq, Skv, Skv_valid;   /* keys >= Skv_valid are masked (context padding 77 -> 80) */
+    int ldq, ldk, ldv, ldo;         /* Q, K, V may be column slices of one fused [tokens][3C] projection */
     float scale;         /* 1/sqrt(64) */
+    int reserved_;
+    const void* zero_page;          /* >= 16 zero bytes, 16-B aligned: source of the direct-to-LDS loads of rows >= Skv */
 } LbAttnParams;
 int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
+void lb_attn_set_tuning(int force);   /* testing: 0 = by shape; bits 0-1 = query groups per wave (1 / 2), bit 4 = always stream 64-key tiles */
 int lb_softmax_rows_f16(void* x, int M, int N, int ld, float scale, void* stream);
 
 /* ---- small kernels ----------------------------------------------------------------- */

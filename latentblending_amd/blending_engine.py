@@ -270,7 +270,7 @@ class BlendingEngine:
         fuse = (use_frontier and self.fuse_anchor_round and self.farm is None and _is_native(self.dh.pipe)
                 and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0 and self.speculate_virtual
                 and len(self.list_idx_injection) == 1 and int(self.list_idx_injection[0]) >= 1
-                and int(self.list_nmb_stems[0]) >= 1)
+                and int(self.list_nmb_stems[0]) >= 1 and self._uniform_cfg())
         if fuse:
             first, last, prefilled = self._anchors_with_first_round()
         elif self.farm is not None and self.farm.world > 1 and not keep1 and not keep2:
@@ -300,6 +300,13 @@ class BlendingEngine:
                     self.insert_into_tree(fract, idx_injection, branch)
         return self.tree_final_imgs
 
+    def _uniform_cfg(self) -> bool:
+        """True when the anchors and every possible mid branch agree on using classifier-free guidance (the mid
+        dampening can push a sub-unity guidance above 1 towards the middle of the transition)."""
+        pipe = self.dh.pipe
+        g_mid = planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper, 0.5)
+        return pipe.uses_cfg(self.guidance_scale_base) == pipe.uses_cfg(g_mid)
+
     def compute_latents1(self, return_image=False):
         """Full trajectory of the first anchor (pure prompt1)."""
         self._say("starting compute_latents1")
@@ -307,6 +314,7 @@ class BlendingEngine:
         t0 = time.time()
         start = self.get_noise(self.seed1)
         traj = self.run_diffusion(cond, latents_start=start, idx_start=0)
+        self._sync()                                     # (native launches are asynchronous)
         self.dt_unet_step = (time.time() - t0) / self.num_inference_steps
         self.tree_latents[0] = traj
         return self.dh.latent2image(traj[-1]) if return_image else traj
@@ -332,7 +340,6 @@ class BlendingEngine:
         """Both anchors as ONE batch-2 denoising run (native pipes; they are independent when the
         first anchor is not crossfed into the second).  Halves the number of weight-streaming
         UNet passes of the anchor phase; results equal the two sequential runs."""
-        t0 = time.time()
         self.dh.set_num_inference_steps(self.num_inference_steps)
         conds = [self.get_mixed_conditioning(0)[0], self.get_mixed_conditioning(1)[0]]
         starts = [self.get_noise(self.seed1), self.get_noise(self.seed2)]
@@ -340,7 +347,7 @@ class BlendingEngine:
         first, last = self.dh.pipe.native_run_diffusion_batch(
             conds, starts, 0, [None, None], [zeros, zeros], num_inference_steps=self.num_inference_steps,
             guidance_scales=[self.guidance_scale, self.guidance_scale])
-        self.dt_unet_step = (time.time() - t0) / self.num_inference_steps
+        # (dt_unet_step keeps its benchmark_speed() value: a batched, asynchronous run is not a per-step timing)
         self.tree_latents[0], self.tree_latents[-1] = first, last
         return first, last
 
@@ -415,7 +422,6 @@ class BlendingEngine:
         are decoded in one batch, and the greedy loop then starts from a pre-filled pool."""
         pipe, steps = self.dh.pipe, self.num_inference_steps
         idx_injection, stems = int(self.list_idx_injection[0]), int(self.list_nmb_stems[0])
-        t0 = time.time()
         self.dh.set_num_inference_steps(steps)
         gaps = self._bfs_midpoints(min(self.frontier_width, stems))
         coeffs = planner.parental_crossfeed_coeffs(steps, idx_injection, self.parental_crossfeed_power,
@@ -426,7 +432,6 @@ class BlendingEngine:
             [self.get_noise(self.seed1), self.get_noise(self.seed2)],
             [self.get_mixed_conditioning(m)[0] for _, _, m in gaps], [m for _, _, m in gaps],
             [coeffs] * len(gaps), idx_injection, steps, self.guidance_scale, guid)
-        self.dt_unet_step = (time.time() - t0) / steps
         frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
         self._tree.reset(first, last, frames[0], frames[1])
         frame_at = {0.0: frames[0], 1.0: frames[1]}

@@ -3,16 +3,28 @@
 //
 //   O[b,q,h,:] = softmax_k( Q[b,q,h,:] . K[b,k,h,:] * scale ) . V[b,k,h,:]
 //
-// Block = 4 waves, 64 query rows (16 per wave); K and V^T tiles of 64 keys are staged in LDS
-// (XOR-swizzled 128-B rows) and shared by the four waves; online softmax in registers.
-// Both products run on v_mfma_f32_16x16x32_f16 with the operands arranged so that NO cross-lane
-// data movement is needed between them:
-//   S^T = K . Q^T   -> lane (q = lane&15, g = lane>>4) holds S for keys {16t + 4g + r}
-//   O^T = V^T . P^T -> the MFMA k-slot (g, j) is mapped to key 32s + 16(j>>2) + 4g + (j&3), which is
-//                      exactly what the lane already holds; V^T rows are read from LDS with the
-//                      same permutation (two 8-byte reads per fragment).
-// V is consumed transposed ([H*64][B*Skv], produced directly by a swapped-operand GEMM), K/Q in
-// the fused-QKV token layout.  Keys >= Skv_valid are masked (cross-attention pads 77 -> 80).
+// Q, K and V are read in their natural token-major layout straight out of the fused QKV projection
+// ([B*S][3C], one GEMM) or, for cross-attention, out of the conditioning program's K|V projection of the
+// text context — no V^T copy exists anywhere.
+//
+// Block = 4 waves; every wave owns 16*QG query rows (QG = 2: 128 rows per block, QG = 1: 64 rows for grids
+// that would not fill the chip).  K and V tiles of KT keys travel global -> LDS with
+// `global_load_lds_dwordx4` (no VGPR round trip, no ds_write pass) through an NS-stage ring with counted
+// `vmcnt` + one raw `s_barrier` per tile, exactly like the GEMM (gemm_glds.hip): tile t+NS-1 is in flight
+// while tile t is consumed.  LDS images are [key][64] fp16 rows of 128 B whose 16-B chunks are XOR-swizzled
+// by (key & 7); the swizzle is applied to the per-lane GLOBAL source address (the LDS side of the DMA is
+// lane-linear).
+//
+// Both products run on v_mfma_f32_16x16x32_f16 with operands arranged so that P never moves between lanes:
+//   S^T = K . Q^T   -> lane (q = lane&15, g = lane>>4) holds S for keys {16 kb + 4g + r}; K fragments are
+//                      conflict-free ds_read_b128 of the swizzled rows; a K/V fragment feeds QG MFMAs.
+//   O^T = V^T . P^T -> MFMA k-slot (g, j) is mapped to key 32 ks + 16 (j>>2) + 4g + (j&3): exactly the keys whose
+//                      probabilities the lane already holds.  The V^T operand comes from the row-major V tile
+//                      through the LDS transpose read `ds_read_b64_tr_b16` (each 16-lane group fetches a
+//                      [4 keys][16 d] block; lane m receives column m), two reads per fragment.
+// Online softmax in the exp2 domain: e = v_exp_f32(fma(s, scale*log2e, -m)); masking (context padding 77 -> 80,
+// ragged last tile) only in the last tile, behind a wave-uniform branch.  KT = 64 streams long sequences;
+// KT = 96 holds a whole short sequence (cross-attention: 80 keys) in ONE tile: no second, mostly empty tile.
 //
 // Replaces diffusers' AttnProcessor2_0 / F.scaled_dot_product_attention inside the UNet call at
 // /root/reference/latentblending/diffusers_holder.py:336.
@@ -20,158 +32,272 @@
 #include "../../include/lb_hip.h"
 
 #define ATT_D 64
-#define ATT_KV 64
 
+typedef __attribute__((address_space(1))) const void* att_gptr_t;
+typedef __attribute__((address_space(3))) void* att_lptr_t;
+typedef __fp16 att_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) att_h4* att_h4_lptr;
+
+template <int N> struct AttInt { static constexpr int value = N; };
+
+template <int N> __device__ __forceinline__ void att_wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// [4 keys][16 d] block of a row-major tile -> lane m of the 16-lane group gets column m (4 keys) (gfx950 LDS transpose
+// read).  Inline asm on purpose: through the builtin the compiler treats the read as a possible alias of the
+// in-flight LDS-DMA of the NEXT tile and drains it with `s_waitcnt vmcnt(0)` every tile.  The reads are therefore
+// invisible to the compiler's wait-count bookkeeping: att_tr_wait<N>() + sched_barrier order them by hand.
+template <int OFF_BYTES> __device__ __forceinline__ f16x4 att_tr_read(unsigned lds_byte_addr) {
+    f16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(OFF_BYTES) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void att_tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // (MFMAs are register-only: keep them below the wait)
+}
+__device__ __forceinline__ unsigned att_lds_addr(const void* p) { return (unsigned)(unsigned long)(att_lptr_t)p; }
+
+template <int KT, int QG, int NS>
 __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p) {
-    __shared__ __attribute__((aligned(16))) f16 lds[2 * 2 * ATT_KV * ATT_D];   // [buf][K | Vt][64][64]
+    constexpr int NKB = KT / 16;            // 16-key blocks of S^T per tile
+    constexpr int NKS = KT / 32;            // 32-key MFMA k-steps of the PV product per tile
+    constexpr int STAGE = 2 * KT * ATT_D;   // halves per ring stage: K tile, then V tile
+    constexpr int NLK = KT * 8 / 256;       // 16-B chunks per thread and operand and tile
+    constexpr int NL = 2 * NLK;             // VMEM->LDS requests per thread and tile
+    extern __shared__ __attribute__((aligned(16))) f16 att_lds[];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q_row = blockIdx.x * 64 + wave * 16 + l16;          // this lane's query (as b-operand col)
+    const int q0 = blockIdx.x * (64 * QG) + wave * (16 * QG);
     const f16* Q = reinterpret_cast<const f16*>(p.Q);
     const f16* K = reinterpret_cast<const f16*>(p.K);
-    const f16* Vt = reinterpret_cast<const f16*>(p.Vt);
+    const f16* V = reinterpret_cast<const f16*>(p.V);
     f16* O = reinterpret_cast<f16*>(p.O);
+    const f16* zero = reinterpret_cast<const f16*>(p.zero_page);
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // Q fragments (b operand): k = d = 32s + 8g .. +8
-    f16x8 qf[2];
+    // ---- loader: thread (r0 = tid>>3 (+32 i), c = tid&7) owns physical chunk c of tile row r0 + 32 i and fetches
+    //      logical chunk c ^ (row & 7); (row & 7) == (r0 & 7) for every i
+    const int r0 = tid >> 3;
+    const int cl = (tid & 7) ^ (r0 & 7);
+    const f16* kbase = K + (long)b * p.Skv * p.ldk + h * ATT_D + cl * 8;
+    const f16* vbase = V + (long)b * p.Skv * p.ldv + h * ATT_D + cl * 8;
+    auto issue_tile = [&](int t, int st) {
+        f16* base = att_lds + st * STAGE;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        qf[s] = zero8;
-        if (q_row < p.Sq)
-            qf[s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
+        for (int i = 0; i < NLK; ++i) {
+            const int key = t * KT + r0 + 32 * i;
+            const f16* src = key < p.Skv ? kbase + (long)key * p.ldk : zero;
+            __builtin_amdgcn_global_load_lds((att_gptr_t)src, (att_lptr_t)(base + (wave * 8 + i * 32) * ATT_D), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            const int key = t * KT + r0 + 32 * i;
+            const f16* src = key < p.Skv ? vbase + (long)key * p.ldv : zero;
+            __builtin_amdgcn_global_load_lds((att_gptr_t)src, (att_lptr_t)(base + KT * ATT_D + (wave * 8 + i * 32) * ATT_D), 16, 0, 0);
+        }
+    };
+
+    const int nt = (p.Skv + KT - 1) / KT;
+    // ---- prologue: the Q fragments (b operand: k = d = 32 s + 8 g .. +8) are requested FIRST (requests retire in
+    //      order: the counted waits of the loop then never wait for a younger request than they mean), then tiles
+    //      0 .. NS-2 go in flight ----
+    f16x8 qf[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const int q_row = q0 + qg * 16 + l16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[qg][s] = zero8;
+            if (q_row < p.Sq)
+                qf[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
+        }
     }
-
-    // staging: thread stages two 16-B chunks of K and two of V^T per tile
-    const int slot = tid & 7, row0 = tid >> 3;                     // rows row0, row0 + 32
-    f16x8 k_reg[2], v_reg[2];
-    const int nt = (p.Skv + ATT_KV - 1) / ATT_KV;
-
-    auto load_tile = [&](int t) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = row0 + i * 32;
-            const int key = t * ATT_KV + r;
-            k_reg[i] = zero8;
-            if (key < p.Skv)
-                k_reg[i] = *reinterpret_cast<const f16x8*>(K + ((long)b * p.Skv + key) * p.ldk + h * ATT_D + slot * 8);
-            const int kcol = t * ATT_KV + slot * 8;                // V^T: row = d, 8 consecutive keys
-            v_reg[i] = zero8;
-            if (kcol < p.Skv)
-                v_reg[i] = *reinterpret_cast<const f16x8*>(Vt + ((long)h * ATT_D + r) * p.ldvt + (long)b * p.Skv + kcol);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        f16* Ks = lds + buf * 2 * ATT_KV * ATT_D;
-        f16* Vs = Ks + ATT_KV * ATT_D;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = row0 + i * 32;
-            *reinterpret_cast<f16x8*>(Ks + r * 64 + ((slot ^ (r & 7)) << 3)) = k_reg[i];
-            *reinterpret_cast<f16x8*>(Vs + r * 64 + ((slot ^ (r & 7)) << 3)) = v_reg[i];
-        }
-    };
+    for (int s = 0; s < NS - 1; ++s) issue_tile(s, s);
 
-    f32x4 ot[4];
+    // ---- loop-invariant LDS offsets (halves, relative to the stage base) ----
+    // K fragment (a operand): row kb*16 + l16, logical chunk s*4 + g
+    int koff[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ot[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int s = 0; s < 2; ++s) koff[s] = l16 * ATT_D + (((s * 4 + g) ^ (l16 & 7)) << 3);
+    // V^T fragment through the transpose read: lane m = l16 supplies the address of key 4g + (m>>2) (+ 16 hh + 32 ks),
+    // d = 16 dt + 4 (m&3): logical chunk 2 dt + ((m&3)>>1), 8-byte half (m&1); swizzle (key & 7) = (4 (g&1) + (m>>2))
+    const int vrow = 4 * g + (l16 >> 2);
+    const int vsw = vrow & 7;
+    int voff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        voff[dt] = KT * ATT_D + vrow * ATT_D + (((2 * dt + ((l16 & 3) >> 1)) ^ vsw) << 3) + (l16 & 1) * 4;
+
+    f32x4 ot[QG][4];
+    float m_run[QG], l_run[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m_run[qg] = -INFINITY;
+        l_run[qg] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[qg][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const float sc = p.scale * 1.44269504088896340736f;           // fold log2(e): exp2 domain
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
+    int st = 0;
     for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
-        const f16* Ks = lds + buf * 2 * ATT_KV * ATT_D;
-        const f16* Vs = Ks + ATT_KV * ATT_D;
+        att_wait_vm_barrier<(NS - 2) * NL>();     // tile t landed everywhere; stage (t-1) % NS is free everywhere
+        {
+            int refill = st - 1;
+            if (refill < 0) refill += NS;
+            issue_tile(t + NS - 1, refill);       // (masked to the zero page past the end: the counts stay constant)
+        }
+        const f16* Ks = att_lds + st * STAGE;
 
         // ---- S^T = K . Q^T ----
-        f32x4 st[4];
+        f32x4 sacc[QG][NKB];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int r = kt * 16 + l16;
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (KT > 64 && kb * 16 >= p.Skv) {    // single-tile form: key blocks beyond the sequence are never computed
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + r * 64 + (((s * 4 + g) ^ (r & 7)) << 3));
-                st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], st[kt], 0, 0, 0);
+                for (int qg = 0; qg < QG; ++qg) sacc[qg][kb] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                continue;
+            }
+            const f16x8 kf0 = *reinterpret_cast<const f16x8*>(Ks + kb * 16 * ATT_D + koff[0]);
+            const f16x8 kf1 = *reinterpret_cast<const f16x8*>(Ks + kb * 16 * ATT_D + koff[1]);
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[qg][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                sacc[qg][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[qg][1], a, 0, 0, 0);
             }
         }
-        // ---- online softmax (this lane: one query, 16 of the tile's 64 keys) ----
-        float mx = -INFINITY;
+        // ---- online softmax (this lane: one query per group, keys 16 kb + 4 g + r of the tile) ----
+        const bool ragged = (t + 1) * KT > p.Skv_valid;           // wave-uniform: only the last tile(s) mask
+        f16x8 pf[QG][NKS];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int qg = 0; qg < QG; ++qg) {
+            if (ragged) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * ATT_KV + kt * 16 + 4 * g + r;
-                const float v = key < p.Skv_valid ? st[kt][r] * sc : -INFINITY;
-                st[kt][r] = v;
-                mx = fmaxf(mx, v);
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (t * KT + kb * 16 + 4 * g + r >= p.Skv_valid) sacc[qg][kb][r] = -INFINITY;
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, LB_WAVE));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, LB_WAVE));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;      // fully masked tile: keep zeros
-        const float alpha = exp2f(m_run - m_use);                  // m_run = -inf -> 0
-        float psum = 0.f;
-        f16x8 pf[2];
+            float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kb = 0; kb < NKB; ++kb)
+                mx = fmaxf(fmaxf(mx, fmaxf(sacc[qg][kb][0], sacc[qg][kb][1])), fmaxf(sacc[qg][kb][2], sacc[qg][kb][3]));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, LB_WAVE));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, LB_WAVE));
+            const float m_new = fmaxf(m_run[qg], mx * sc);        // sc > 0: max commutes with the scaling
+            const float m_use = m_new == -INFINITY ? 0.f : m_new; // fully masked so far: keep zeros
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_use);   // m_run = -inf -> 0
+            float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = exp2f(st[kt][r] - m_use);
-                psum += e;
-                pf[kt >> 1][(kt & 1) * 4 + r] = (f16)e;
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][kb][r], sc, -m_use));
+                    psum += e;
+                    pf[qg][kb >> 1][(kb & 1) * 4 + r] = (f16)e;
+                }
+            l_run[qg] = l_run[qg] * alpha + psum;
+            m_run[qg] = m_new;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
-
-        // ---- O^T += V^T . P^T ----
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int r = dt * 16 + l16;
+                for (int r = 0; r < 4; ++r) ot[qg][dt][r] *= alpha;
+        }
+        // ---- O^T += V^T . P^T ----  (V^T fragments of k-step ks+1 are requested before the MFMAs of k-step ks)
+        {
+            const unsigned vb = att_lds_addr(Ks);
+            f16x4 vlo[NKS][4], vhi[NKS][4];
+            auto request = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                // keys 32s + 4g + {0..3} and 32s + 16 + 4g + {0..3}
-                const int c_lo = s * 4 + (g >> 1), c_hi = c_lo + 2;
-                const f16x4 lo = *reinterpret_cast<const f16x4*>(Vs + r * 64 + ((c_lo ^ (r & 7)) << 3) + (g & 1) * 4);
-                const f16x4 hi = *reinterpret_cast<const f16x4*>(Vs + r * 64 + ((c_hi ^ (r & 7)) << 3) + (g & 1) * 4);
-                const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s], ot[dt], 0, 0, 0);
+                for (int dt = 0; dt < 4; ++dt) {
+                    vlo[ks][dt] = att_tr_read<(32 * ks) * ATT_D * 2>(vb + voff[dt] * 2);
+                    vhi[ks][dt] = att_tr_read<(32 * ks + 16) * ATT_D * 2>(vb + voff[dt] * 2);
+                }
+            };
+            auto multiply = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f16x8 vf = {vlo[ks][dt][0], vlo[ks][dt][1], vlo[ks][dt][2], vlo[ks][dt][3],
+                                      vhi[ks][dt][0], vhi[ks][dt][1], vhi[ks][dt][2], vhi[ks][dt][3]};
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+                        ot[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qg][ks], ot[qg][dt], 0, 0, 0);
+                }
+            };
+            request(AttInt<0>{});
+            request(AttInt<1>{});
+            att_tr_wait<8>();
+            multiply(AttInt<0>{});
+            if constexpr (NKS == 3) {
+                request(AttInt<2>{});        // (keys 64..95: zero rows / zero probabilities when the sequence is shorter)
+                att_tr_wait<8>();
+                multiply(AttInt<1>{});
+                att_tr_wait<0>();
+                multiply(AttInt<2>{});
+            } else {
+                att_tr_wait<0>();
+                multiply(AttInt<1>{});
             }
         }
-        if (t + 1 < nt) store_tile(buf ^ 1);
-        __syncthreads();
+        st = st + 1 == NS ? 0 : st + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before the block may exit
 
-    l_run += __shfl_xor(l_run, 16, LB_WAVE);
-    l_run += __shfl_xor(l_run, 32, LB_WAVE);
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    if (q_row < p.Sq) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const f16x4 o = {(f16)(ot[dt][0] * inv), (f16)(ot[dt][1] * inv), (f16)(ot[dt][2] * inv),
-                             (f16)(ot[dt][3] * inv)};
-            *reinterpret_cast<f16x4*>(O + ((long)b * p.Sq + q_row) * p.ldo + h * ATT_D + dt * 16 + 4 * g) = o;
+    for (int qg = 0; qg < QG; ++qg) {
+        float l = l_run[qg];
+        l += __shfl_xor(l, 16, LB_WAVE);
+        l += __shfl_xor(l, 32, LB_WAVE);
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const int q_row = q0 + qg * 16 + l16;
+        if (q_row < p.Sq) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f16x4 o = {(f16)(ot[qg][dt][0] * inv), (f16)(ot[qg][dt][1] * inv), (f16)(ot[qg][dt][2] * inv),
+                                 (f16)(ot[qg][dt][3] * inv)};
+                *reinterpret_cast<f16x4*>(O + ((long)b * p.Sq + q_row) * p.ldo + h * ATT_D + dt * 16 + 4 * g) = o;
+            }
         }
     }
+}
+
+template <int KT, int QG, int NS>
+static void attn_launch(const LbAttnParams& p, hipStream_t s) {
+    const size_t smem = (size_t)NS * 2 * KT * ATT_D * sizeof(f16);
+    const dim3 grid((p.Sq + 64 * QG - 1) / (64 * QG), p.H, p.B);
+    hipLaunchKernelGGL((attn_fwd_d64_kernel<KT, QG, NS>), grid, dim3(256), smem, s, p);
+}
+
+// variant (testing): 0 = by shape, else bit 0..1 QG (1 / 2), bit 4 forces the 64-key streaming tile
+static int g_attn_force = 0;
+extern "C" void lb_attn_set_tuning(int force) { g_attn_force = force; }
+
+static int attn_dispatch(const LbAttnParams& p, int force, hipStream_t s) {
+    // short sequences (cross-attention: 80 context rows) sit in ONE 96-key tile; long ones stream 64-key tiles
+    const bool single = p.Skv <= 96 && !(force & 16);
+    int qg = force & 3;
+    if (qg == 0) qg = (long)((p.Sq + 127) / 128) * p.H * p.B >= 384 ? 2 : 1;   // 128-row blocks once they fill the chip
+    if (single) { if (qg == 2) attn_launch<96, 2, 2>(p, s); else attn_launch<96, 1, 2>(p, s); }
+    else        { if (qg == 2) attn_launch<64, 2, 3>(p, s); else attn_launch<64, 1, 3>(p, s); }
+    return lb_check_launch("lb_attn_fwd_d64");
 }
 
 extern "C" int lb_attn_fwd_d64(const LbAttnParams* pp, void* stream) {
     const LbAttnParams p = *pp;
     LB_REQUIRE(p.B > 0 && p.H > 0 && p.Sq > 0 && p.Skv > 0, "lb_attn_fwd_d64: sizes");
-    LB_REQUIRE(p.Skv % 8 == 0 && p.Skv_valid > 0 && p.Skv_valid <= p.Skv, "lb_attn_fwd_d64: Skv % 8, valid");
-    LB_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldvt % 8 == 0 && p.ldo % 4 == 0, "lb_attn_fwd_d64: ld alignment");
-    dim3 grid((p.Sq + 63) / 64, p.H, p.B);
-    LB_DISPATCH_STMT("lb_attn_fwd_d64", hipLaunchKernelGGL(attn_fwd_d64_kernel, grid, dim3(256), 0, s, p));
+    LB_REQUIRE(p.Skv_valid > 0 && p.Skv_valid <= p.Skv, "lb_attn_fwd_d64: 0 < Skv_valid <= Skv");
+    LB_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "lb_attn_fwd_d64: ld alignment");
+    LB_REQUIRE(p.zero_page != nullptr, "lb_attn_fwd_d64: zero_page (>= 16 zero bytes) is required");
+    const int force = g_attn_force;
+    LB_DISPATCH("lb_attn_fwd_d64", attn_dispatch(p, force, s));
 }
 
 // ------------------------------------------------------------------------------------------

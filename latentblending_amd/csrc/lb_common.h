@@ -77,8 +77,26 @@ __device__ __forceinline__ f16 lb_f64_to_f16(double x) {
     return (f16)f;
 }
 
-__device__ __forceinline__ float lb_silu(float x) { return x / (1.0f + __expf(-x)); }
+// SiLU / erf-GELU for epilogues and bandwidth-bound passes: raw v_exp_f32 / v_rcp_f32 (1 ulp), no IEEE division
+// sequence, no libm call.  x -> -inf: exp2 -> inf, rcp -> 0, x * 0 = -0;  x -> +inf: exp2 -> 0, result x.
+__device__ __forceinline__ float lb_silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output rounding): branch-free,
+// 1 rcp + 1 exp2 + 8 FMA-class ops instead of the ~40-instruction libm erff with its two branches.
+__device__ __forceinline__ float lb_erf(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
+    const float r = __builtin_fmaf(-p * t, e, 1.0f);
+    return __builtin_copysignf(r, x);
+}
 
 __device__ __forceinline__ float lb_gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + lb_erf(x * 0.70710678118654752440f));
 }

@@ -101,6 +101,11 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const T* __restrict__ x
     }
 }
 
+// Apply pass.  Like the statistics pass every thread owns a FIXED 8-channel vector (v = tid % vecs, pixel row
+// r = tid / vecs) and walks the pixels of its chunk: the affine transform of its channels is folded ONCE into
+// y = x * scale + shift (scale = rstd * gamma, shift = beta - mean * scale; 16 registers), so the streaming loop is
+// one 16-B load, 8 FMAs (+ SiLU) and one 16-B store per vector.  (Round 1 re-read gamma / beta / mean / rstd per
+// vector: four extra VMEM requests and 16 LDS reads per 16 bytes of payload - the pass ran at 2.4 TB/s.)
 template <typename T>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
                                                        const double* __restrict__ partial,
@@ -108,7 +113,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
                                                        const float* __restrict__ beta,
                                                        f16* __restrict__ y, int HW, int C, int ldx,
                                                        int ldy, int groups, int nchunk, float eps,
-                                                       int silu) {
+                                                       int silu, int chunk_px) {
     __shared__ float mean_s[GN_MAX_GROUPS], rstd_s[GN_MAX_GROUPS];
     __shared__ double fold_s[8][GN_MAX_GROUPS], fold_q[8][GN_MAX_GROUPS];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -140,50 +145,52 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const T* __restrict__ x,
     }
     __syncthreads();
     const int vecs = C >> 3;
-    const long items = (long)HW * vecs;
-    const long stride = (long)gridDim.x * 256;
-    auto finish = [&](const float (&val)[8], long i) {
-        const int px = (int)(i / vecs);
-        const int c0 = (int)(i - (long)px * vecs) * 8;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
-        int grp = c0 / cpg;
-        int left = (grp + 1) * cpg - c0;
-        f16x8 o;
+    const int rows = vecs <= 256 ? 256 / vecs : 1;
+    const int px_begin = blockIdx.x * chunk_px;
+    int px_end = px_begin + chunk_px;
+    if (px_end > HW) px_end = HW;
+    const int r = vecs <= 256 ? tid / vecs : 0;
+    if (vecs <= 256 && tid >= rows * vecs) return;
+    for (int v = vecs <= 256 ? tid % vecs : tid; v < vecs; v += 256) {
+        const int c0 = v * 8;
+        float sc[8], sh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            if (left == 0) { ++grp; left = cpg; }
-            --left;
-            const float ga = e < 4 ? g0[e & 3] : g1[e & 3];
-            const float be = e < 4 ? b0[e & 3] : b1[e & 3];
-            float t = (val[e] - mean_s[grp]) * rstd_s[grp] * ga + be;
-            if (silu) t = lb_silu(t);
-            o[e] = (f16)t;
+            const int grp = (c0 + e) / cpg;
+            const float a = rstd_s[grp] * gamma[c0 + e];
+            sc[e] = a;
+            sh[e] = beta[c0 + e] - mean_s[grp] * a;
         }
-        *reinterpret_cast<f16x8*>(y + ((long)b * HW + px) * ldy + c0) = o;
-    };
-    auto src = [&](long i) {
-        const long px = i / vecs;
-        return x + ((long)b * HW + px) * ldx + (i - px * vecs) * 8;
-    };
-    long i = (long)blockIdx.x * 256 + tid;
-    for (; i + 3 * stride < items; i += 4 * stride) {          // four independent 16-B requests in flight
-        float v0[8], v1[8], v2[8], v3[8];
-        load8<T>(src(i), v0);
-        load8<T>(src(i + stride), v1);
-        load8<T>(src(i + 2 * stride), v2);
-        load8<T>(src(i + 3 * stride), v3);
-        finish(v0, i);
-        finish(v1, i + stride);
-        finish(v2, i + 2 * stride);
-        finish(v3, i + 3 * stride);
-    }
-    for (; i < items; i += stride) {
-        float val[8];
-        load8<T>(src(i), val);
-        finish(val, i);
+        const T* src = x + ((long)b * HW) * ldx + c0;
+        f16* dst = y + ((long)b * HW) * ldy + c0;
+        auto finish = [&](const float (&val)[8], int px) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = __builtin_fmaf(val[e], sc[e], sh[e]);
+                if (silu) t = lb_silu(t);
+                o[e] = (f16)t;
+            }
+            *reinterpret_cast<f16x8*>(dst + (long)px * ldy) = o;
+        };
+        int px = px_begin + r;
+        for (; px + 3 * rows < px_end; px += 4 * rows) {          // four independent 16-B requests in flight
+            float v0[8], v1[8], v2[8], v3[8];
+            load8<T>(src + (long)px * ldx, v0);
+            load8<T>(src + (long)(px + rows) * ldx, v1);
+            load8<T>(src + (long)(px + 2 * rows) * ldx, v2);
+            load8<T>(src + (long)(px + 3 * rows) * ldx, v3);
+            finish(v0, px);
+            finish(v1, px + rows);
+            finish(v2, px + 2 * rows);
+            finish(v3, px + 3 * rows);
+        }
+        for (; px < px_end; px += rows) {
+            float val[8];
+            load8<T>(src + (long)px * ldx, val);
+            finish(val, px);
+        }
+        if (vecs <= 256) break;
     }
 }
 
@@ -217,15 +224,19 @@ static int groupnorm_impl(const void* x, void* y, const float* gamma, const floa
 #undef GN_PART
     int rc = lb_check_launch("lb_groupnorm_nhwc(partial)");
     if (rc) return rc;
-    long bx = ((long)HW * vecs + 255) / 256;
-    if (bx > 1024) bx = 1024;
-    dim3 grid2((unsigned)bx, B);
+    // apply pass: ~4096 blocks per launch (finer chunks than the statistics pass: no partials to fold per chunk)
+    int want2 = (4096 + B - 1) / B;
+    int apx = (HW + want2 - 1) / want2;
+    const int min_px = 4 * rows;
+    if (apx < min_px) apx = min_px;
+    const int achunks = (HW + apx - 1) / apx;
+    dim3 grid2((unsigned)achunks, B);
     if (x_is_f32)
         hipLaunchKernelGGL((gn_apply_kernel<float>), grid2, dim3(256), 0, stream, (const float*)x,
-                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu);
+                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu, apx);
     else
         hipLaunchKernelGGL((gn_apply_kernel<f16>), grid2, dim3(256), 0, stream, (const f16*)x,
-                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu);
+                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, nchunk, eps, silu, apx);
     return lb_check_launch("lb_groupnorm_nhwc(apply)");
 }
 

@@ -37,10 +37,10 @@ class LbGemmParams(C.Structure):
 
 class LbAttnParams(C.Structure):
     _fields_ = [
-        ("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("Sq", C.c_int), ("Skv", C.c_int), ("Skv_valid", C.c_int),
-        ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
-        ("scale", C.c_float),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
+        ("scale", C.c_float), ("reserved_", C.c_int), ("zero_page", C.c_void_p),
     ]
 
 
@@ -74,6 +74,7 @@ SIGNATURES = {
     "lb_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "lb_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lb_attn_fwd_d64": (_i, [C.POINTER(LbAttnParams), _vp]),
+    "lb_attn_set_tuning": (None, [_i]),
     "lb_softmax_rows_f16": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "lb_sinusoid_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lb_copy_cols_f16": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
@@ -101,7 +102,7 @@ SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

@@ -217,17 +217,29 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 # ------------------------------------------------------------------------------ attention --
-def attention_d64(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
-                  skv_valid: Optional[int] = None, ldq=None, ldk=None, ldvt=None,
+_ZERO_PAGES = {}
+
+
+def zero_page(device) -> torch.Tensor:
+    """64 zero bytes per device: the source of masked direct-to-LDS loads (GEMM tails, attention rows >= Skv)."""
+    key = str(device)
+    if key not in _ZERO_PAGES:
+        _ZERO_PAGES[key] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return _ZERO_PAGES[key]
+
+
+def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
+                  skv_valid: Optional[int] = None, ldq=None, ldk=None, ldv=None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q: [B*Sq, >=H*64], k: [B*Skv, >=H*64], vt: [H*64, >=B*Skv] (row strides may exceed widths)."""
+    """q: [B*Sq, >=H*64], k, v: [B*Skv, >=H*64] (row strides may exceed widths: slices of a fused QKV buffer)."""
     p = LbAttnParams()
     if out is None:
         out = torch.empty(B * Sq, H * 64, dtype=F16, device=q.device)
-    p.Q, p.K, p.Vt, p.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, skv_valid or Skv
-    p.ldq, p.ldk, p.ldvt, p.ldo = ldq or q.stride(0), ldk or k.stride(0), ldvt or vt.stride(0), out.stride(0)
+    p.ldq, p.ldk, p.ldv, p.ldo = ldq or q.stride(0), ldk or k.stride(0), ldv or v.stride(0), out.stride(0)
     p.scale = 0.125
+    p.zero_page = zero_page(q.device).data_ptr()
     api.lb_attn_fwd_d64(C.byref(p), stream_ptr())
     return out
 

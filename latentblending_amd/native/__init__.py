@@ -2,7 +2,7 @@
 from .pipe import NativeSDXLPipe, StableDiffusionXLPipeline
 from .unet import NativeUNet, UNetConfig
 from .vae import NativeVAEDecoder, VAEConfig
-from .weights import DictProvider, SyntheticProvider, from_safetensors
+from .weights import DictProvider, SyntheticProvider, from_safetensors, lpips_provider
 
 __all__ = ["NativeSDXLPipe", "StableDiffusionXLPipeline", "NativeUNet", "UNetConfig", "NativeVAEDecoder",
-           "VAEConfig", "DictProvider", "SyntheticProvider", "from_safetensors"]
+           "VAEConfig", "DictProvider", "SyntheticProvider", "from_safetensors", "lpips_provider"]

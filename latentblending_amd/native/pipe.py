@@ -20,7 +20,10 @@ seeded synthetic embeddings of the right shapes unless ``text_encoder_fn`` is su
 """
 from __future__ import annotations
 
+import os
+import warnings
 import zlib
+from collections import OrderedDict
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -100,7 +103,11 @@ class StableDiffusionXLPipeline:
                  vae_cfg: Optional[VAEConfig] = None, unet_provider=None, vae_provider=None,
                  lpips_provider=None, device="cuda", seed: int = 0, name_or_path: Optional[str] = None,
                  text_encoder_fn=None, unet_native: Optional[NativeUNet] = None,
-                 vae_native: Optional[NativeVAEDecoder] = None):
+                 vae_native: Optional[NativeVAEDecoder] = None, allow_synthetic: Optional[bool] = None):
+        """``allow_synthetic``: seeded synthetic stand-ins (UNet / VAE / LPIPS weights when no provider is given,
+        prompt embeddings when no ``text_encoder_fn`` is given) are used silently when True (tests, bench: also
+        ``LB_ALLOW_SYNTHETIC=1``); otherwise each stand-in announces itself ONCE with a ``UserWarning`` - frames
+        rendered from them are noise-like and prompts have no semantic effect."""
         if not torch.cuda.is_available():
             raise RuntimeError("NativeSDXLPipe needs an MI355X (HIP device); there is no CPU fallback")
         self.device = torch.device(device)
@@ -111,6 +118,15 @@ class StableDiffusionXLPipeline:
         self._name_or_path = name_or_path or ("stabilityai/sdxl-turbo" if turbo else
                                               "stabilityai/stable-diffusion-xl-base-1.0")
         self.dtype = F16
+        self.allow_synthetic = bool(allow_synthetic) if allow_synthetic is not None else os.environ.get("LB_ALLOW_SYNTHETIC") == "1"
+        self._warned = set()
+        if unet_native is None and unet_provider is None:
+            self._synthetic_notice("UNet weights", "pass unet_provider=native.from_safetensors(<dir>/unet) or set LB_WEIGHTS_DIR")
+        if vae_native is None and vae_provider is None:
+            self._synthetic_notice("VAE weights", "pass vae_provider=native.from_safetensors(<dir>/vae) or set LB_WEIGHTS_DIR")
+        if lpips_provider is None:
+            self._synthetic_notice("LPIPS-Alex weights (the branch-insertion metric is then NOT LPIPS)",
+                                   "pass lpips_provider=native.lpips_provider(alexnet_state_dict, lpips_lin_state_dict)")
         self.unet_native = unet_native or NativeUNet(self.unet_cfg, unet_provider or SyntheticProvider(seed), self.device)
         self.vae_native = vae_native or NativeVAEDecoder(self.vae_cfg, vae_provider or SyntheticProvider(seed + 1), self.device)
         self.lpips_metric = NativeLPIPS(lpips_provider or SyntheticProvider(7), self.device)
@@ -129,11 +145,21 @@ class StableDiffusionXLPipeline:
         self._denoising_end = None
         self._interrupt = False
         self._num_timesteps = 0
-        self._unet_programs: Dict[Tuple[int, int], UNetProgram] = {}
-        self._vae_programs: Dict[Tuple[int, int], VAEProgram] = {}
+        # recorded launch programs, keyed by (batch, latent side); each owns its activation arena (+ hipGraph), so the
+        # caches are LRU-bounded: speculative rounds of varying width must not pile up SDXL-sized arenas
+        self._unet_programs: "OrderedDict[Tuple[int, int], UNetProgram]" = OrderedDict()
+        self._vae_programs: "OrderedDict[Tuple[int, int], VAEProgram]" = OrderedDict()
+        self.max_cached_programs = 8
         self._use_graphs = False
         self._feat_scratch: Dict[int, list] = {}
         self.stats = {"unet_forwards": 0, "unet_samples": 0, "vae_decodes": 0, "slerps": 0, "lpips_pairs": 0}
+
+    def _synthetic_notice(self, what: str, how: str):
+        if self.allow_synthetic or what in self._warned:
+            return
+        self._warned.add(what)
+        warnings.warn(f"NativeSDXLPipe: using seeded SYNTHETIC {what} ({how}; allow_synthetic=True silences this)",
+                      UserWarning, stacklevel=3)
 
     # ---- diffusers duck type ------------------------------------------------------------
     guidance_scale = property(lambda s: s._guidance_scale)
@@ -143,6 +169,9 @@ class StableDiffusionXLPipeline:
     @property
     def do_classifier_free_guidance(self):
         return self._guidance_scale > 1 and self.unet.config.time_cond_proj_dim is None
+
+    def uses_cfg(self, guidance_scale: float) -> bool:
+        return float(guidance_scale) > 1 and self.unet.config.time_cond_proj_dim is None
 
     def to(self, *_a, **_k):
         return self
@@ -161,6 +190,8 @@ class StableDiffusionXLPipeline:
             if self.text_encoder_fn is not None:
                 pe, pooled = self.text_encoder_fn(text)
             else:
+                self._synthetic_notice("prompt embeddings (prompts have no semantic effect)",
+                                       "pass text_encoder_fn=native.clip.NativeTextEncoders(...).encode")
                 pe = _synthetic_embedding(text, (1, 77, c.cross_dim), 1)
                 pooled = _synthetic_embedding(text, (1, c.pooled_dim), 2)
             return pe.to(self.device, F16), pooled.to(self.device, F16)
@@ -190,23 +221,31 @@ class StableDiffusionXLPipeline:
         return torch.tensor([ids], dtype=dtype, device=self.device)
 
     # ---- programs -----------------------------------------------------------------------
+    def _cached(self, cache: OrderedDict, key, build):
+        if key in cache:
+            cache.move_to_end(key)
+            return cache[key]
+        while len(cache) >= max(1, self.max_cached_programs):
+            torch.cuda.synchronize(self.device)          # (its launches may still be in flight on the stream)
+            cache.popitem(last=False)                    # least recently used: arena, workspaces and graph go with it
+        cache[key] = build()
+        return cache[key]
+
     def unet_program(self, B: int, L: int) -> UNetProgram:
-        key = (B, L)
-        if key not in self._unet_programs:
+        def build():
             prog = self.unet_native.build(B, L)
             if self._use_graphs:
                 prog.enable_graphs()
-            self._unet_programs[key] = prog
-        return self._unet_programs[key]
+            return prog
+        return self._cached(self._unet_programs, (B, L), build)
 
     def vae_program(self, B: int, L: int) -> VAEProgram:
-        key = (B, L)
-        if key not in self._vae_programs:
+        def build():
             prog = self.vae_native.build(B, L)
             if self._use_graphs:
                 prog.prog.instantiate()
-            self._vae_programs[key] = prog
-        return self._vae_programs[key]
+            return prog
+        return self._cached(self._vae_programs, (B, L), build)
 
     def enable_graphs(self, flag: bool = True):
         self._use_graphs = bool(flag)
@@ -240,8 +279,21 @@ class StableDiffusionXLPipeline:
         sched = self.scheduler
         if sched.num_inference_steps != num_inference_steps:
             sched.set_timesteps(num_inference_steps)
+        # classifier-free guidance is a per-branch predicate in the reference (guidance_scale > 1,
+        # diffusers_holder.py:80,282): a batch mixing both kinds is run as two homogeneous sub-batches
+        wants = [self.uses_cfg(g) for g in guidance_scales]
+        if any(wants) and not all(wants):
+            out: List[Optional[list]] = [None] * G
+            for flag in (False, True):
+                idx = [g for g in range(G) if wants[g] == flag]
+                part = self.native_run_diffusion_batch([conds[g] for g in idx], [starts[g] for g in idx], idx_start,
+                                                       [mixings[g] for g in idx], [coeffs_list[g] for g in idx],
+                                                       num_inference_steps, [guidance_scales[g] for g in idx])
+                for g, traj in zip(idx, part):
+                    out[g] = traj
+            return out
         self._guidance_scale = float(guidance_scales[-1])
-        cfg = max(float(g) for g in guidance_scales) > 1 and self.unet.config.time_cond_proj_dim is None
+        cfg = wants[0]
         L = starts[0].shape[-1]
         per_sample = starts[0][0].numel()
         prog = self.unet_program(G * (2 if cfg else 1), L)
@@ -318,7 +370,8 @@ class StableDiffusionXLPipeline:
             sched.set_timesteps(steps)
         all_g = [float(guidance_anchor)] * A + [float(g) for g in guidance_mids]
         self._guidance_scale = all_g[-1]
-        cfg = max(all_g) > 1 and self.unet.config.time_cond_proj_dim is None
+        cfg = self.uses_cfg(all_g[0])
+        assert all(self.uses_cfg(g) == cfg for g in all_g), "wavefront batches must be uniformly CFG or non-CFG"
         mul = 2 if cfg else 1
         L = anchor_starts[0].shape[-1]
         per_sample = anchor_starts[0][0].numel()

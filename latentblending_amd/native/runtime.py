@@ -204,13 +204,14 @@ class Emitter:
                              eps, _stream())
         return out
 
-    def attention(self, q_ptr: int, k_ptr: int, vt_ptr: int, out: torch.Tensor, *, B, H, Sq, Skv, valid,
-                  ldq, ldk, ldvt, ldo):
+    def attention(self, q_ptr: int, k_ptr: int, v_ptr: int, out: torch.Tensor, *, B, H, Sq, Skv, valid,
+                  ldq, ldk, ldv, ldo):
         p = LbAttnParams()
-        p.Q, p.K, p.Vt, p.O = q_ptr, k_ptr, vt_ptr, out.data_ptr()
+        p.Q, p.K, p.V, p.O = q_ptr, k_ptr, v_ptr, out.data_ptr()
         p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, valid
-        p.ldq, p.ldk, p.ldvt, p.ldo = ldq, ldk, ldvt, ldo
+        p.ldq, p.ldk, p.ldv, p.ldo = ldq, ldk, ldv, ldo
         p.scale = 0.125
+        p.zero_page = self.zero_page.data_ptr()
         api.lb_attn_fwd_d64(C.byref(p), _stream())
         self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * 64})
         return out

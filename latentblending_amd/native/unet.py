@@ -11,10 +11,10 @@ MI355X-specific here:
   stride-2 downsampling are folded into the conv's gather;
 * work that does not depend on the image is batched into a few fat GEMMs instead of hundreds of
   tiny launches: all 17 resnets' time-embedding projections = 1 GEMM; all 70 cross-attention
-  K projections = 1 GEMM and all V^T projections = 1 GEMM over the (padded) text context, kept
-  in a separate *conditioning program* that only re-runs when the conditioning changes;
-* V is produced directly transposed by swapping the GEMM operands (out = W_v . X^T), which is
-  the layout the attention kernel's second MFMA consumes without any cross-lane traffic;
+  K and V projections of the (padded) text context = 1 GEMM (N = 166,400), kept in a separate
+  *conditioning program* that only re-runs when the conditioning changes;
+* Q, K and V of a self-attention come out of ONE [tokens, 3C] projection and the attention kernel reads the
+  three column slices in place (V through the LDS transpose read): no V^T copy, one launch instead of two;
 * the whole forward is recorded once per (batch, latent size) and replayed from C++ / hipGraph.
 """
 from __future__ import annotations
@@ -130,8 +130,8 @@ class NativeUNet:
             self._norm(pv, b + ".norm1", c)
             q = self._linear(pv, b + ".attn1.to_q", c, c, bias=False, keep_host=True)
             k = self._linear(pv, b + ".attn1.to_k", c, c, bias=False, keep_host=True)
-            self.w[b + ".attn1.qk"] = self._dev(torch.cat([q, k], 0), F16)
-            self._linear(pv, b + ".attn1.to_v", c, c, bias=False)
+            v = self._linear(pv, b + ".attn1.to_v", c, c, bias=False, keep_host=True)
+            self.w[b + ".attn1.qkv"] = self._dev(torch.cat([q, k, v], 0), F16)      # one [3C, C] projection
             self._linear(pv, b + ".attn1.to_out.0", c, c, gain=0.5)
             self._norm(pv, b + ".norm2", c)
             self._linear(pv, b + ".attn2.to_q", c, c, bias=False)
@@ -203,8 +203,8 @@ class NativeUNet:
         # fused projections
         self.w["temb_proj.weight"] = self._dev(torch.cat(temb_acc["w"], 0), F16)
         self.w["temb_proj.bias"] = self._dev(torch.cat(temb_acc["b"], 0), F32)
-        self.w["ctx_k.weight"] = self._dev(torch.cat(ctx_acc["k"], 0), F16)
-        self.w["ctx_v.weight"] = self._dev(torch.cat(ctx_acc["v"], 0), F16)
+        # every cross-attention K projection, then every V projection, of the text context: ONE [2 n_ctx, X] weight
+        self.w["ctx_kv.weight"] = self._dev(torch.cat(ctx_acc["k"] + ctx_acc["v"], 0), F16)
         self.n_temb, self.n_ctx = temb_acc["n"], ctx_acc["n"]
 
     def weight_bytes(self) -> int:
@@ -235,8 +235,7 @@ class UNetProgram:
         self.eps = torch.zeros(B, cfg.out_channels, L, L, dtype=F16, device=dev)
         # ---- conditioning-program outputs (persistent) ----
         self.aug = torch.zeros(B, T, dtype=F16, device=dev)
-        self.ctx_k = torch.zeros(B * CTX_PAD, net.n_ctx, dtype=F16, device=dev)
-        self.ctx_vt = torch.zeros(net.n_ctx, B * CTX_PAD, dtype=F16, device=dev)
+        self.ctx_kv = torch.zeros(B * CTX_PAD, 2 * net.n_ctx, dtype=F16, device=dev)   # [K of all blocks | V of all blocks]
         self.prog_cond = Program("unet-cond")
         self.prog_step = Program("unet-step")
         with self.prog_cond.record():
@@ -309,16 +308,13 @@ class UNetProgram:
             # --- self attention ---
             ln = ar.alloc((M, c))
             em.layernorm(h, ln, w[b + ".norm1.weight"], w[b + ".norm1.bias"], M=M, C_=c)
-            qk = ar.alloc((M, 2 * c))
-            em.gemm(ln, w[b + ".attn1.qk"], qk, M=M)
-            vt = ar.alloc((c, M))
-            em.gemm(w[b + ".attn1.to_v.weight"], ln, vt, M=c)            # V^T = W_v . X^T
+            qkv = ar.alloc((M, 3 * c))
+            em.gemm(ln, w[b + ".attn1.qkv"], qkv, M=M)                  # Q | K | V in one launch
             ar.release(ln)
             a = ar.alloc((M, c))
-            em.attention(qk.data_ptr(), qk.data_ptr() + c * 2, vt.data_ptr(), a, B=B, H=heads, Sq=S, Skv=S,
-                         valid=S, ldq=2 * c, ldk=2 * c, ldvt=M, ldo=c)
-            ar.release(qk)
-            ar.release(vt)
+            em.attention(qkv.data_ptr(), qkv.data_ptr() + c * 2, qkv.data_ptr() + 2 * c * 2, a, B=B, H=heads, Sq=S,
+                         Skv=S, valid=S, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c)
+            ar.release(qkv)
             em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h)
             ar.release(a)
             # --- cross attention (K / V^T of the text context come from the conditioning program) ---
@@ -329,9 +325,9 @@ class UNetProgram:
             ar.release(ln)
             off, _ = self.net.ctx_slices[b]
             a = ar.alloc((M, c))
-            em.attention(q.data_ptr(), self.ctx_k.data_ptr() + off * 2,
-                         self.ctx_vt.data_ptr() + off * (B * CTX_PAD) * 2, a, B=B, H=heads, Sq=S, Skv=CTX_PAD,
-                         valid=CTX_TOKENS, ldq=c, ldk=self.net.n_ctx, ldvt=B * CTX_PAD, ldo=c)
+            em.attention(q.data_ptr(), self.ctx_kv.data_ptr() + off * 2,
+                         self.ctx_kv.data_ptr() + (self.net.n_ctx + off) * 2, a, B=B, H=heads, Sq=S, Skv=CTX_PAD,
+                         valid=CTX_TOKENS, ldq=c, ldk=2 * self.net.n_ctx, ldv=2 * self.net.n_ctx, ldo=c)
             ar.release(q)
             em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h)
             ar.release(a)
@@ -364,8 +360,7 @@ class UNetProgram:
         ar.release(add_in)
         ar.release(a1)
         ctx2d = self.ctx.view(B * CTX_PAD, cfg.cross_dim)
-        em.gemm(ctx2d, w["ctx_k.weight"], self.ctx_k, M=B * CTX_PAD)
-        em.gemm(w["ctx_v.weight"], ctx2d, self.ctx_vt, M=self.net.n_ctx)
+        em.gemm(ctx2d, w["ctx_kv.weight"], self.ctx_kv, M=B * CTX_PAD)
 
     # ---- step program: depends on the latent and the timestep
     def _emit_step(self):

@@ -92,3 +92,31 @@ def from_safetensors(path: str, prefix: str = "") -> DictProvider:
     for f in files:
         state.update(load_file(f))
     return DictProvider(state, prefix)
+
+
+# AlexNet trunk conv indices inside torchvision's ``alexnet().features`` / the slices of ``lpips.pretrained_networks.alexnet``
+_ALEX_FEATURE_IDX = (0, 3, 6, 8, 10)
+
+
+def lpips_provider(alexnet_state: Dict[str, torch.Tensor], lin_state: Dict[str, torch.Tensor]) -> DictProvider:
+    """Provider for ``NativeLPIPS`` from REAL checkpoints: the torchvision AlexNet trunk (keys ``features.N.weight`` /
+    ``.bias``, or the ``net.sliceK.N.*`` names the same tensors carry inside a saved ``lpips.LPIPS`` module) and the
+    learned linear layers of ``lpips`` v0.1 (``linK.model.1.weight``, shape [1, C, 1, 1]; the file
+    ``lpips/weights/v0.1/alex.pth``).  The reference builds exactly this net with ``lpips.LPIPS(net='alex')``
+    (/root/reference/latentblending/blending_engine.py:73-76)."""
+    out: Dict[str, torch.Tensor] = {}
+    for i, idx in enumerate(_ALEX_FEATURE_IDX):
+        for kind in ("weight", "bias"):
+            for key in (f"features.{idx}.{kind}", f"net.slice{i + 1}.{idx}.{kind}", f"net.features.{idx}.{kind}"):
+                if key in alexnet_state:
+                    out[f"net.conv{i + 1}.{kind}"] = alexnet_state[key]
+                    break
+            else:
+                raise KeyError(f"AlexNet conv {i + 1} ({kind}): none of features.{idx}.{kind} / net.slice{i + 1}.{idx}.{kind} found")
+        for key in (f"lin{i}.model.1.weight", f"lin{i}.weight", f"lins.{i}.model.1.weight"):
+            if key in lin_state:
+                out[f"lin{i}.weight"] = lin_state[key].reshape(-1)
+                break
+        else:
+            raise KeyError(f"LPIPS linear layer {i}: lin{i}.model.1.weight not found")
+    return DictProvider(out)

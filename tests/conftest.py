@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("LB_ALLOW_SYNTHETIC", "1")     # tests run on seeded synthetic weights / embeddings by design
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

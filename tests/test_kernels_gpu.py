@@ -360,9 +360,33 @@ def test_attention_d64(case, results_log):
     C = H * 64
     q, k, v = rnd(B, Sq, C, seed=51), rnd(B, Skv, C, seed=52), rnd(B, Skv, C, seed=53)
     ref = R.attention(q.float(), k.float()[:, :valid], v.float()[:, :valid], H)
-    vt = v.reshape(B * Skv, C).t().contiguous()                    # [C, B*Skv]
-    got = o.attention_d64(q.reshape(B * Sq, C).to(DEV), k.reshape(B * Skv, C).to(DEV), vt.to(DEV), B, H, Sq, Skv, valid)
+    got = o.attention_d64(q.reshape(B * Sq, C).to(DEV), k.reshape(B * Skv, C).to(DEV), v.reshape(B * Skv, C).to(DEV),
+                          B, H, Sq, Skv, valid)
     check_close(results_log, f"attn_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
+
+
+@pytest.mark.parametrize("force", [1, 2, 17, 18])
+@pytest.mark.parametrize("case", [(2, 3, 300, 300, 300), (2, 2, 130, 80, 77), (1, 2, 70, 96, 90), (1, 1, 16, 8, 5)])
+def test_attention_d64_variants(case, force, results_log):
+    """Every kernel variant (1 / 2 query groups per wave, single 96-key tile / streamed 64-key tiles) on ragged shapes,
+    with Q, K and V read as column slices of ONE fused [tokens][3C] buffer (the UNet's layout)."""
+    o, l = ops(), lib()
+    B, H, Sq, Skv, valid = case
+    C = H * 64
+    q, k, v = rnd(B, Sq, C, seed=61), rnd(B, Skv, C, seed=62), rnd(B, Skv, C, seed=63)
+    ref = R.attention(q.float(), k.float()[:, :valid], v.float()[:, :valid], H)
+    if Sq == Skv:
+        qkv = torch.cat([q, k, v], dim=-1).reshape(B * Sq, 3 * C).to(DEV)
+        qd, kd, vd = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    else:
+        kv = torch.cat([k, v], dim=-1).reshape(B * Skv, 2 * C).to(DEV)
+        qd, kd, vd = q.reshape(B * Sq, C).to(DEV), kv[:, :C], kv[:, C:]
+    l.api.lb_attn_set_tuning(force)
+    try:
+        got = o.attention_d64(qd, kd, vd, B, H, Sq, Skv, valid)
+    finally:
+        l.api.lb_attn_set_tuning(0)
+    check_close(results_log, f"attn_f{force}_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
 
 
 def test_attention_spiked_scores(results_log):
@@ -374,8 +398,7 @@ def test_attention_spiked_scores(results_log):
     k[0, 200] = q[0, 3] * 6.0          # one key far above the rest, in the last tile
     k[0, 70] = q[0, 100] * 4.0
     ref = R.attention(q.float(), k.float(), v.float(), H)
-    got = o.attention_d64(q.reshape(S, C).to(DEV), k.reshape(S, C).to(DEV), v.reshape(S, C).t().contiguous().to(DEV),
-                          B, H, S, S)
+    got = o.attention_d64(q.reshape(S, C).to(DEV), k.reshape(S, C).to(DEV), v.reshape(S, C).to(DEV), B, H, S, S)
     check_close(results_log, "attn_spiked", got.reshape(B, S, C), ref, floor=2e-3)
 
 
