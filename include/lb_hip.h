@@ -46,6 +46,11 @@ int lb_slerp_pairs_f64(const void* const* p0, const void* const* p1, void* const
 /* contiguous batch [npairs][n] with device-side fracts: the HBM-roofline form (6 B/element). */
 int lb_slerp_batched_f16(const void* p0, const void* p1, void* out, const double* fracts_dev,
                          long npairs, long n, void* stream);
+/* the same with ELEMENT strides between consecutive pairs of each input (0 = all pairs share that tensor: the
+ * parental mix of one pair of anchor latents at npairs fractions, blending_engine.py:443-450); out is
+ * [npairs][n] contiguous; n % 8 == 0, n <= 32768 (L <= 90). */
+int lb_slerp_strided_f16(const void* p0, long stride0, const void* p1, long stride1, void* out,
+                         const double* fracts_dev, long npairs, long n, void* stream);
 
 /* latentblending/utils.py:97 interpolate_linear on tensors (blending_engine.py:650) */
 int lb_lerp_f16(const void* p0, const void* p1, void* out, long n, double fract, void* stream);

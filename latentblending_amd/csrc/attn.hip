@@ -22,8 +22,11 @@
 //                      probabilities the lane already holds.  The V^T operand comes from the row-major V tile
 //                      through the LDS transpose read `ds_read_b64_tr_b16` (each 16-lane group fetches a
 //                      [4 keys][16 d] block; lane m receives column m), two reads per fragment.
-// Online softmax in the exp2 domain: e = v_exp_f32(fma(s, scale*log2e, -m)); masking (context padding 77 -> 80,
-// ragged last tile) only in the last tile, behind a wave-uniform branch.  KT = 64 streams long sequences;
+// Online softmax in the exp2 domain: e = v_exp_f32(fma(s, scale*log2e, -m)) with a DEFERRED rescale (the running
+// maximum moves only when a query outgrows it by 2^8), row sums on the matrix pipe (an all-ones V^T block);
+// masking (context padding 77 -> 80, ragged last tile) only in the last tile, behind a wave-uniform branch.
+// Built with -fno-honor-nans (no canonicalising v_max around every fmaxf) and the VGPR form of the MFMAs
+// (accumulators are VALU operands of the softmax: no v_accvgpr_read / _write traffic).  KT = 64 streams long sequences;
 // KT = 96 holds a whole short sequence (cross-attention: 80 keys) in ONE tile: no second, mostly empty tile.
 //
 // Replaces diffusers' AttnProcessor2_0 / F.scaled_dot_product_attention inside the UNet call at
@@ -32,6 +35,7 @@
 #include "../../include/lb_hip.h"
 
 #define ATT_D 64
+#define ATT_DEFER 8.0f      // log2 units: the running max is only raised when a score exceeds it by more than this
 
 typedef __attribute__((address_space(1))) const void* att_gptr_t;
 typedef __attribute__((address_space(3))) void* att_lptr_t;
@@ -134,15 +138,19 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
     for (int dt = 0; dt < 4; ++dt)
         voff[dt] = KT * ATT_D + vrow * ATT_D + (((2 * dt + ((l16 & 3) >> 1)) ^ vsw) << 3) + (l16 & 1) * 4;
 
-    f32x4 ot[QG][4];
-    float m_run[QG], l_run[QG];
+    // O^T accumulators plus ONE extra 16-row block whose V^T operand is all ones: its rows accumulate the softmax
+    // denominators sum_k P[q][k] on the (under-used) matrix pipe instead of 32 VALU adds per tile, from the very
+    // fp16-rounded probabilities the numerator uses, already summed over all keys (no cross-lane reduction at the end)
+    f32x4 ot[QG][4], lt[QG];
+    float m_run[QG];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         m_run[qg] = -INFINITY;
-        l_run[qg] = 0.f;
+        lt[qg] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) ot[qg][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
     const float sc = p.scale * 1.44269504088896340736f;           // fold log2(e): exp2 domain
 
     int st = 0;
@@ -190,24 +198,28 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
                 mx = fmaxf(fmaxf(mx, fmaxf(sacc[qg][kb][0], sacc[qg][kb][1])), fmaxf(sacc[qg][kb][2], sacc[qg][kb][3]));
             mx = fmaxf(mx, __shfl_xor(mx, 16, LB_WAVE));
             mx = fmaxf(mx, __shfl_xor(mx, 32, LB_WAVE));
-            const float m_new = fmaxf(m_run[qg], mx * sc);        // sc > 0: max commutes with the scaling
-            const float m_use = m_new == -INFINITY ? 0.f : m_new; // fully masked so far: keep zeros
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_use);   // m_run = -inf -> 0
-            float psum = 0.f;
+            // deferred rescale: the running maximum only moves (and O, l are only rescaled) when some query of the wave
+            // outgrew it by more than 2^ATT_DEFER; otherwise probabilities are taken against the old maximum and stay
+            // <= 2^ATT_DEFER (exact in the fp32 accumulators, the same relative precision in fp16)
+            const float m_cand = mx * sc;                          // sc > 0: max commutes with the scaling
+            if (__any(m_cand > m_run[qg] + ATT_DEFER)) {
+                const float m_new = fmaxf(m_run[qg], m_cand);
+                const float m_fin = m_new == -INFINITY ? 0.f : m_new;          // fully masked so far: keep zeros
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_fin); // m_run = -inf -> 0
+                m_run[qg] = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[qg][dt][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lt[qg][r] *= alpha;
+            }
+            const float m_use = m_run[qg] == -INFINITY ? 0.f : m_run[qg];
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][kb][r], sc, -m_use));
-                    psum += e;
-                    pf[qg][kb >> 1][(kb & 1) * 4 + r] = (f16)e;
-                }
-            l_run[qg] = l_run[qg] * alpha + psum;
-            m_run[qg] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ot[qg][dt][r] *= alpha;
+                for (int r = 0; r < 4; ++r)
+                    pf[qg][kb >> 1][(kb & 1) * 4 + r] = (f16)__builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qg][kb][r], sc, -m_use));
         }
         // ---- O^T += V^T . P^T ----  (V^T fragments of k-step ks+1 are requested before the MFMAs of k-step ks)
         {
@@ -231,6 +243,9 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
                     for (int qg = 0; qg < QG; ++qg)
                         ot[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qg][ks], ot[qg][dt], 0, 0, 0);
                 }
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    lt[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[qg][ks], lt[qg], 0, 0, 0);
             };
             request(AttInt<0>{});
             request(AttInt<1>{});
@@ -253,9 +268,7 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
 
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        float l = l_run[qg];
-        l += __shfl_xor(l, 16, LB_WAVE);
-        l += __shfl_xor(l, 32, LB_WAVE);
+        const float l = lt[qg][0];                                 // (every row of the ones-block holds the same sum)
         const float inv = l > 0.f ? 1.f / l : 0.f;
         const int q_row = q0 + qg * 16 + l16;
         if (q_row < p.Sq) {

@@ -15,6 +15,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result", "-I", HERE]
 
 
+# per-source extra flags (see the header comment of the file for the reason)
+EXTRA_FLAGS = {"attn.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
 
@@ -33,8 +37,8 @@ def _needs(obj, deps):
 def _compile(src):
     obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
     headers = [os.path.join(HERE, h) for h in os.listdir(HERE) if h.endswith(".h")]
-    if _needs(obj, [os.path.join(HERE, src)] + headers):
-        cmd = [_hipcc(), *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+    if _needs(obj, [os.path.join(HERE, src), os.path.abspath(__file__)] + headers):
+        cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -56,6 +56,22 @@ __device__ __forceinline__ void slerp_weights(double dot, double n0sq, double n1
     w1 = sin(tt) / st;
 }
 
+// The weights are a few hundred dependent float64 instructions (sqrt, acos, three sin, divisions): ONE thread
+// evaluates them and publishes them through LDS while the other waves of the block sleep at the barrier, so the
+// CU's VALU stays free for the other resident blocks (every thread used to evaluate them redundantly).
+__device__ __forceinline__ void slerp_weights_block(double dot, double n0sq, double n1sq, double fract,
+                                                    double& w0, double& w1, double* red) {
+    if (threadIdx.x == 0) {
+        double a, b;
+        slerp_weights(dot, n0sq, n1sq, fract, a, b);
+        red[52] = a;
+        red[53] = b;
+    }
+    __syncthreads();
+    w0 = red[52];
+    w1 = red[53];
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void slerp_body(const T* __restrict__ p0, const T* __restrict__ p1,
                                            typename OutOf<T>::type* __restrict__ out, long n,
@@ -85,7 +101,7 @@ __device__ __forceinline__ void slerp_body(const T* __restrict__ p0, const T* __
     }
     block_sum3(dot, s0, s1, red);
     double w0, w1;
-    slerp_weights(dot, s0, s1, fract, w0, w1);
+    slerp_weights_block(dot, s0, s1, fract, w0, w1, red);
     for (long i = threadIdx.x; i < nvec; i += blockDim.x) {
         VT a, b;
         if (staged) {
@@ -129,6 +145,54 @@ __global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict_
     const long b = blockIdx.x;
     slerp_body<T, VEC>(p0 + b * n, p1 + b * n, out + b * n, n, fracts[b], stage0, stage1,
                        staged != 0, red);
+}
+
+// Batch of pairs with element strides between consecutive pairs (0 = every pair reads the same tensor: the
+// parental mix of ONE pair of anchors at many fractions) and device-side fractions.  Each thread keeps its
+// VPT 16-byte vectors of both inputs in REGISTERS between the reduction and the weighted sum: HBM is read exactly
+// once (6 B / element) without an LDS round trip, the block needs 0.5 KiB of LDS, so four 512-thread blocks share a
+// CU and one block's loads overlap another's float64 arithmetic.
+template <int VPT>
+__global__ void __launch_bounds__(512) slerp_strided_kernel(const f16* __restrict__ p0, long stride0,
+                                                             const f16* __restrict__ p1, long stride1,
+                                                             f16* __restrict__ out, const double* __restrict__ fracts,
+                                                             long n) {
+    __shared__ double red[64];
+    const long b = blockIdx.x;
+    const f16* a0 = p0 + b * stride0;
+    const f16* b0 = p1 + b * stride1;
+    f16* o = out + b * n;
+    const long nvec = n >> 3;
+    f16x8 va[VPT], vb[VPT];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const long i = threadIdx.x + (long)j * 512;
+        va[j] = i < nvec ? *reinterpret_cast<const f16x8*>(a0 + i * 8) : zero8;
+        vb[j] = i < nvec ? *reinterpret_cast<const f16x8*>(b0 + i * 8) : zero8;
+    }
+    double dot = 0, s0 = 0, s1 = 0;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double x = (double)va[j][e], y = (double)vb[j][e];
+            dot += x * y; s0 += x * x; s1 += y * y;
+        }
+    block_sum3(dot, s0, s1, red);
+    double w0, w1;
+    slerp_weights_block(dot, s0, s1, fracts[b], w0, w1, red);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const long i = threadIdx.x + (long)j * 512;
+        if (i < nvec) {
+            f16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                r[e] = lb_f64_to_f16(__dadd_rn(__dmul_rn((double)va[j][e], w0), __dmul_rn((double)vb[j][e], w1)));
+            *reinterpret_cast<f16x8*>(o + i * 8) = r;
+        }
+    }
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -187,8 +251,12 @@ extern "C" int lb_slerp_pairs_f64(const void* const* p0, const void* const* p1, 
     LB_DISPATCH("lb_slerp_pairs_f64", slerp_chunks_impl<double>(chunks, n, s));
 }
 
+static int slerp_strided_impl(const void* p0, long stride0, const void* p1, long stride1, void* out,
+                              const double* fracts_dev, long npairs, long n, hipStream_t stream);
+
 static int slerp_batched_impl(const void* p0, const void* p1, void* out, const double* fracts_dev,
                               long npairs, long n, hipStream_t stream) {
+    if (n <= 512 * 8 * 8) return slerp_strided_impl(p0, n, p1, n, out, fracts_dev, npairs, n, stream);
     const size_t stage_bytes = (size_t)n * 2 * sizeof(f16);
     const int staged = stage_bytes <= 128 * 1024 ? 1 : 0;
     const size_t smem = 512 + (staged ? stage_bytes : 0);
@@ -202,6 +270,28 @@ static int slerp_batched_impl(const void* p0, const void* p1, void* out, const d
     hipLaunchKernelGGL(kern, dim3((unsigned)npairs), dim3(512), smem, stream,
                        (const f16*)p0, (const f16*)p1, (f16*)out, fracts_dev, n, staged);
     return lb_check_launch("lb_slerp_batched_f16");
+}
+
+static int slerp_strided_impl(const void* p0, long stride0, const void* p1, long stride1, void* out,
+                              const double* fracts_dev, long npairs, long n, hipStream_t stream) {
+    const long nvec = n >> 3;
+    const dim3 grid((unsigned)npairs), block(512);
+#define LB_SLERP_STRIDED(V) hipLaunchKernelGGL((slerp_strided_kernel<V>), grid, block, 0, stream, (const f16*)p0, stride0, \
+                                               (const f16*)p1, stride1, (f16*)out, fracts_dev, n)
+    if (nvec <= 512) LB_SLERP_STRIDED(1);
+    else if (nvec <= 1024) LB_SLERP_STRIDED(2);
+    else if (nvec <= 2048) LB_SLERP_STRIDED(4);
+    else LB_SLERP_STRIDED(8);
+#undef LB_SLERP_STRIDED
+    return lb_check_launch("lb_slerp_strided_f16");
+}
+
+extern "C" int lb_slerp_strided_f16(const void* p0, long stride0, const void* p1, long stride1, void* out,
+                                    const double* fracts_dev, long npairs, long n, void* stream) {
+    LB_REQUIRE(npairs > 0 && n > 0 && n % 8 == 0 && n <= 512 * 8 * 8, "lb_slerp_strided_f16: n multiple of 8, <= 32768");
+    LB_REQUIRE(stride0 % 8 == 0 && stride1 % 8 == 0 && stride0 >= 0 && stride1 >= 0, "lb_slerp_strided_f16: strides multiples of 8");
+    LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_slerp_strided_f16: 16-B alignment");
+    LB_DISPATCH("lb_slerp_strided_f16", slerp_strided_impl(p0, stride0, p1, stride1, out, fracts_dev, npairs, n, s));
 }
 
 extern "C" int lb_slerp_batched_f16(const void* p0, const void* p1, void* out,

@@ -57,6 +57,7 @@ SIGNATURES = {
     "lb_slerp_pairs_f32": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
     "lb_slerp_pairs_f64": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
     "lb_slerp_batched_f16": (_i, [_vp, _vp, _vp, _vp, _l, _l, _vp]),
+    "lb_slerp_strided_f16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _l, _vp]),
     "lb_lerp_f16": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_lerp_f32": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_scale_model_input_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),

@@ -63,6 +63,19 @@ def slerp_batched(p0: torch.Tensor, p1: torch.Tensor, fracts_dev: torch.Tensor) 
     return out
 
 
+def slerp_strided(p0: torch.Tensor, p1: torch.Tensor, fracts_dev: torch.Tensor, n: int,
+                  broadcast0: bool = False, broadcast1: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[g] = slerp(p0[g or 0], p1[g or 0], fracts_dev[g]) for g < len(fracts_dev); inputs fp16, contiguous
+    [G, n] (or one tensor of n elements when broadcast); fracts_dev float64 on device.  One launch, no host pointers."""
+    G = fracts_dev.numel()
+    assert p0.dtype == F16 and p1.dtype == F16 and fracts_dev.dtype == F64 and p0.is_contiguous() and p1.is_contiguous()
+    if out is None:
+        out = torch.empty(G, n, dtype=F16, device=p0.device)
+    api.lb_slerp_strided_f16(p0.data_ptr(), 0 if broadcast0 else n, p1.data_ptr(), 0 if broadcast1 else n, out.data_ptr(),
+                             fracts_dev.data_ptr(), G, n, stream_ptr())
+    return out
+
+
 def lerp(p0: torch.Tensor, p1: torch.Tensor, fract: float) -> torch.Tensor:
     a, b = p0.contiguous(), p1.contiguous()
     if a.dtype == F16 and b.dtype == F16:

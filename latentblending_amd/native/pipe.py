@@ -410,25 +410,26 @@ class StableDiffusionXLPipeline:
         lat_m = None
         traj_a = [[], []]
         traj_m: List[List[Optional[torch.Tensor]]] = [[None] * idx_injection for _ in range(G)]
-        fr = [float(f) for f in mid_fracts]
+        # mixing fractions / crossfeed coefficients live on the device: every step's parental mix (ONE pair of anchor
+        # latents at G fractions) and crossfeed (G pairs) is one strided-slerp launch, no host pointer tables
+        n_lat = per_sample
+        fr_dev = torch.tensor([float(f) for f in mid_fracts], dtype=torch.float64, device=self.device) if G else None
+        coef_dev = torch.tensor([[float(mid_coeffs[g][i]) for g in range(G)] for i in range(steps)],
+                                dtype=torch.float64, device=self.device) if G else None
         for i in range(steps):
             if i < idx_injection:
                 prog, lat, params, n = prog_a, lat_a, par_a[i], A
                 noise = noise_a[i] if noise_a is not None else None
             else:
-                prev1, prev2 = traj_a[0][i - 1], traj_a[1][i - 1]
-                mix_prev = ops.slerp_pairs([prev1] * G, [prev2] * G, fr)              # parental mix of step i-1
+                prev1, prev2 = traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous()
+                mix_prev = ops.slerp_strided(prev1, prev2, fr_dev, n_lat, broadcast0=True, broadcast1=True)   # parental mix of step i-1
                 self.stats["slerps"] += G
                 if i == idx_injection:
-                    lat_m = torch.cat(mix_prev)
-                feed = [g for g in range(G) if mid_coeffs[g][i] > 0]
-                if feed:
-                    outs = ops.slerp_pairs([lat_m[g:g + 1] for g in feed], [mix_prev[g] for g in feed],
-                                           [float(mid_coeffs[g][i]) for g in feed])
-                    self.stats["slerps"] += len(feed)
-                    lat_m = lat_m.clone()
-                    for g, o in zip(feed, outs):
-                        lat_m[g:g + 1] = o
+                    lat_m = mix_prev.view(G, *lat_a.shape[1:])
+                nfeed = sum(1 for g in range(G) if mid_coeffs[g][i] > 0)
+                if nfeed:       # (a coefficient of 0 returns the first operand bit-exactly, like the reference's skipped slerp)
+                    lat_m = ops.slerp_strided(lat_m.contiguous().view(G, n_lat), mix_prev, coef_dev[i], n_lat).view(G, *lat_a.shape[1:])
+                    self.stats["slerps"] += nfeed
                 prog, lat, params, n = prog_all, torch.cat([lat_a, lat_m]), par_all[i - idx_injection], A + G
                 noise = torch.cat([noise_a[i], noise_m[i - idx_injection]]) if noise_a is not None else None
             api.lb_scale_model_input_f16(lat.data_ptr(), prog.x_in.data_ptr(), params.data_ptr(), per_sample, n,

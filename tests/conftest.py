@@ -31,5 +31,14 @@ def results_log():
     yield log
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_metrics.json"), "w") as fh:
-        json.dump(log, fh, indent=1, sort_keys=True)
+    path = os.path.join(out, "parity_metrics.json")
+    merged = {}
+    if os.path.isfile(path):                 # several pytest invocations of one GPU call add up
+        try:
+            with open(path) as fh:
+                merged = json.load(fh)
+        except Exception:
+            merged = {}
+    merged.update(log)
+    with open(path, "w") as fh:
+        json.dump(merged, fh, indent=1, sort_keys=True)

@@ -114,6 +114,28 @@ def test_slerp_batched(results_log):
             assert ulp_diff_f16(got[i], R.slerp(p0[i], p1[i], float(fr[i]))) <= 1
 
 
+@pytest.mark.parametrize("n", [4096, 16384, 32768, 8 * 37])
+def test_slerp_strided(n, results_log):
+    """One launch for G pairs with device-side fractions: contiguous batches, a broadcast pair (the parental mix of
+    two anchors at many fractions) and the fract = 0 / 1 end points, bit-identical to the per-pair kernel."""
+    o = ops()
+    G = 9
+    a, b = rnd(G, n, seed=71), rnd(G, n, seed=72)
+    fr = [0.0, 1.0, 0.5, 0.25, 0.37, 0.8, 0.1234, 0.9, 0.6]
+    frd = torch.tensor(fr, dtype=torch.float64, device=DEV)
+    got = o.slerp_strided(a.to(DEV), b.to(DEV), frd, n).cpu()
+    ref = torch.stack([R.slerp(a[g], b[g], fr[g]) for g in range(G)])
+    per_pair = torch.stack([t.cpu() for t in o.slerp_pairs([a[g].to(DEV) for g in range(G)], [b[g].to(DEV) for g in range(G)], fr)])
+    assert torch.equal(got, per_pair)
+    assert torch.equal(got[0], a[0]) and torch.equal(got[1], b[1])
+    u = ulp_diff_f16(got, ref)
+    got_b = o.slerp_strided(a[0].to(DEV), b[0].to(DEV), frd, n, broadcast0=True, broadcast1=True).cpu()
+    ref_b = torch.stack([R.slerp(a[0], b[0], f) for f in fr])
+    ub = ulp_diff_f16(got_b, ref_b)
+    results_log[f"slerp_strided_n{n}"] = {"ulp": u, "ulp_broadcast": ub}
+    assert u <= 1 and ub <= 1
+
+
 def test_lerp_bit_exact(results_log):
     o = ops()
     a, b = rnd(1, 77, 2048, seed=11), rnd(1, 77, 2048, seed=12)
