@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+GEMM_OPS = ("lb_gemm_f16", "lb_conv3x3_halo_f16")      # one kernel family: MFMA GEMM / implicit-GEMM conv / halo-tile conv
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
 
@@ -68,7 +69,7 @@ def gemm_family_profile(pipe, launches):
             up = pipe.unet_program(B, L)
             progs = [(up.prog_step, count)]
             em = up.em
-            n_cond_gemms = sum(1 for n in up.prog_cond.op_names() if n == "lb_gemm_f16")
+            n_cond_gemms = sum(1 for n in up.prog_cond.op_names() if n in GEMM_OPS)
             logs = {id(up.prog_step): (em.gemm_log[n_cond_gemms:], em.attn_log)}
         else:
             vp = pipe.vae_program(B, L)
@@ -82,7 +83,7 @@ def gemm_family_profile(pipe, launches):
             gi = ai = 0
             for n, t in zip(names, ms):
                 tot["all_ms"] += t * cnt
-                if n == "lb_gemm_f16":
+                if n in GEMM_OPS:
                     tot["gemm_flops"] += glog[gi]["flops"] * cnt
                     tot["gemm_bytes"] += glog[gi]["bytes"] * cnt
                     tot["gemm_ms"] += t * cnt

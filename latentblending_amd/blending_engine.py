@@ -235,6 +235,9 @@ class BlendingEngine:
             t_compute_max_allowed = 20
         elif t_compute_max_allowed is not None and nmb_max_branches is not None:
             raise ValueError("Either specify t_compute_max_allowed or nmb_max_branches")
+        if self._farm_on() and t_compute_max_allowed is not None:
+            # a time budget is planned from measured step times: every rank must plan from the SAME numbers
+            self.dt_unet_step, self.dt_vae = self.farm.broadcast_floats([self.dt_unet_step, self.dt_vae], src=0)
         self.list_idx_injection, self.list_nmb_stems = self.get_time_based_branching(
             depth_strength, t_compute_max_allowed, nmb_max_branches)
 
@@ -267,20 +270,28 @@ class BlendingEngine:
         keep1 = recycle_img1 and len(self.tree_latents[0]) == steps
         keep2 = recycle_img2 and len(self.tree_latents[-1]) == steps
         prefilled = None
-        fuse = (use_frontier and self.fuse_anchor_round and self.farm is None and _is_native(self.dh.pipe)
-                and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0 and self.speculate_virtual
-                and len(self.list_idx_injection) == 1 and int(self.list_idx_injection[0]) >= 1
-                and int(self.list_nmb_stems[0]) >= 1 and self._uniform_cfg())
-        if fuse:
-            first, last, prefilled = self._anchors_with_first_round()
-        elif self.farm is not None and self.farm.world > 1 and not keep1 and not keep2:
-            first, last = self._anchors_distributed()
-        elif use_frontier and _is_native(self.dh.pipe) and not keep1 and not keep2 \
-                and self.branch1_crossfeed_power == 0.0:
-            first, last = self._compute_anchors_batched()
-        else:
-            first = self.tree_latents[0] if keep1 else self.compute_latents1()
-            last = self.tree_latents[-1] if keep2 else self.compute_latents2()
+        restore_noise = self._farm_begin(keep1, keep2) if self._farm_on() else None
+        try:
+            fuse = (use_frontier and self.fuse_anchor_round and _is_native(self.dh.pipe)
+                    and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0 and self.speculate_virtual
+                    and len(self.list_idx_injection) == 1 and int(self.list_idx_injection[0]) >= 1
+                    and int(self.list_nmb_stems[0]) >= 1 and self._uniform_cfg())
+            if fuse:
+                first, last, prefilled = self._anchors_with_first_round()
+            elif self._farm_on():
+                first, last = self._anchors_distributed(keep1, keep2)
+            elif use_frontier and _is_native(self.dh.pipe) and not keep1 and not keep2 \
+                    and self.branch1_crossfeed_power == 0.0:
+                first, last = self._compute_anchors_batched()
+            else:
+                first = self.tree_latents[0] if keep1 else self.compute_latents1()
+                last = self.tree_latents[-1] if keep2 else self.compute_latents2()
+            return self._grow_tree(first, last, prefilled, use_frontier)
+        finally:
+            if restore_noise is not None:
+                restore_noise()
+
+    def _grow_tree(self, first, last, prefilled, use_frontier):
 
         if prefilled is None:
             frames = self._decode_many([first[-1], last[-1]])
@@ -299,6 +310,33 @@ class BlendingEngine:
                     branch = self.compute_latents_mix(fract, p1, p2, idx_injection)
                     self.insert_into_tree(fract, idx_injection, branch)
         return self.tree_final_imgs
+
+    # ------------------------------------------------------------------ farm (SPMD) ---------
+    def _farm_on(self) -> bool:
+        return self.farm is not None and self.farm.world > 1
+
+    def _farm_begin(self, keep1, keep2):
+        """Start of a farmed transition: (1) every rank must hold the same plan and settings — checked with one tiny
+        all-gather, so a divergence stops here with a message instead of hanging in a later collective whose shapes
+        depend on the plan; (2) ancestral noise must be the same stream on every rank (ranks compute anchors
+        redundantly and branches independently): unless the user installed a noise source, rank 0 draws a seed,
+        broadcasts it, and every rank samples from a device generator seeded with it for this transition.
+        Returns a callable that restores the pipe's noise source, or None."""
+        plan = [float(v) for v in self.list_idx_injection] + [-1.0] + [float(v) for v in self.list_nmb_stems] + [
+            float(self.num_inference_steps), float(self.frontier_width), float(self.guidance_scale_base),
+            float(self.branch1_crossfeed_power), float(self.parental_crossfeed_power), float(self.parental_crossfeed_range),
+            float(self.parental_crossfeed_decay), float(self.seed1), float(self.seed2), float(bool(keep1)), float(bool(keep2))]
+        self.farm.check_consistent(plan, "branching plan / settings")
+        sched = getattr(self.dh.pipe, "scheduler", None)
+        if _is_native(self.dh.pipe) and getattr(sched, "ancestral", False) and sched.noise_source is None:
+            from .native.scheduler import SeededDeviceNoise
+            seed = int(self.farm.broadcast_floats([float(np.random.randint(0, 2 ** 31 - 1))], src=0)[0])
+            sched.noise_source = SeededDeviceNoise(seed, self.dh.pipe.device)
+
+            def restore():
+                sched.noise_source = None
+            return restore
+        return None
 
     def _uniform_cfg(self) -> bool:
         """True when the anchors and every possible mid branch agree on using classifier-free guidance (the mid
@@ -427,20 +465,28 @@ class BlendingEngine:
         coeffs = planner.parental_crossfeed_coeffs(steps, idx_injection, self.parental_crossfeed_power,
                                                    self.parental_crossfeed_range, self.parental_crossfeed_decay)
         guid = [planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper, m) for _, _, m in gaps]
+        # farm: every rank runs BOTH anchors (no exchange, no idle ranks) plus its round-robin share of the mids
+        farm = self.farm if self._farm_on() else None
+        mine = farm.my_indices(len(gaps)) if farm else list(range(len(gaps)))
         first, last, mids = pipe.native_run_wavefront(
             [self.get_mixed_conditioning(0)[0], self.get_mixed_conditioning(1)[0]],
             [self.get_noise(self.seed1), self.get_noise(self.seed2)],
-            [self.get_mixed_conditioning(m)[0] for _, _, m in gaps], [m for _, _, m in gaps],
-            [coeffs] * len(gaps), idx_injection, steps, self.guidance_scale, guid)
+            [self.get_mixed_conditioning(gaps[k][2])[0] for k in mine], [gaps[k][2] for k in mine],
+            [coeffs] * len(mine), idx_injection, steps, self.guidance_scale, [guid[k] for k in mine],
+            noise_slots=(len(gaps), mine) if farm else None)
         frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
         self._tree.reset(first, last, frames[0], frames[1])
+        mid_frames = frames[2:]
+        if farm:
+            got = farm.exchange_branches(list(zip(mids, mid_frames)), len(gaps), steps - idx_injection, steps,
+                                         self._frame_from_u8, self._latent_chw(), (self.dh.height_img, self.dh.width_img))
+            mids, mid_frames = [self._on_pipe_device(t) for t, _ in got], [f for _, f in got]
+            for k in mine:                      # keep this rank's own frame objects (their LPIPS features may be cached)
+                mid_frames[k] = frames[2 + mine.index(k)]
         frame_at = {0.0: frames[0], 1.0: frames[1]}
-        frame_at.update({m: f for (_, _, m), f in zip(gaps, frames[2:])})
-        pairs = []
-        for (fl, fr, m) in gaps:
-            pairs += [(frame_at[m], frame_at[fl]), (frame_at[m], frame_at[fr])]
-        sims = self._frame_distances(pairs)
-        ready = {(fl, fr): dict(fract=m, traj=traj, frame=frame_at[m], sl=sims[2 * k], sr=sims[2 * k + 1])
+        frame_at.update({m: f for (_, _, m), f in zip(gaps, mid_frames)})
+        sims = self._gap_child_distances([(frame_at[m], frame_at[fl], frame_at[fr]) for (fl, fr, m) in gaps])
+        ready = {(fl, fr): dict(fract=m, traj=traj, frame=frame_at[m], sl=sims[k][0], sr=sims[k][1])
                  for k, ((fl, fr, m), traj) in enumerate(zip(gaps, mids))}
         self.guidance_scale = self.dh.guidance_scale = guid[-1]
         self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
@@ -507,27 +553,51 @@ class BlendingEngine:
                         heapq.heappush(heap, (-float(e), tick, a, b, g))
                         tick += 1
             # 3) evaluate (batched on a native pipe, split over the ranks of a farm), then score
-            if self.farm is not None and self.farm.world > 1:
-                mine = self._evaluate_specs(specs[self.farm.rank::self.farm.world], idx_injection)
-                results = self.farm.exchange_branches([(t, f, 0.0, 0.0) for t, f in mine], len(specs),
-                                                      self.num_inference_steps - idx_injection,
-                                                      self.num_inference_steps, make_frame=self._frame_from_u8)
-                results = [(self._on_pipe_device(t), f) for t, f, _, _ in results]
+            if self._farm_on():
+                own = self.farm.my_indices(len(specs))
+                mine = self._evaluate_specs(specs, idx_injection, only=own)
+                got = self.farm.exchange_branches(mine, len(specs), self.num_inference_steps - idx_injection,
+                                                  self.num_inference_steps, self._frame_from_u8, self._latent_chw(),
+                                                  (self.dh.height_img, self.dh.width_img))
+                results = [(self._on_pipe_device(t), f) for t, f in got]
+                for k, r in zip(own, mine):     # keep this rank's own frame objects
+                    results[k] = (results[k][0], r[1])
             else:
                 results = self._evaluate_specs(specs, idx_injection)
             frame_at = {f: tree.frames[i] for i, f in enumerate(tree.fracts)}
             frame_at.update({r["fract"]: r["frame"] for r in ready.values()})
             frame_at.update({s["fract"]: fr_ for s, (_, fr_) in zip(specs, results)})
-            pairs = []
-            for s, (_, frame) in zip(specs, results):
-                pairs += [(frame, frame_at[s["left"]]), (frame, frame_at[s["right"]])]
-            sims = self._frame_distances(pairs)
+            sims = self._gap_child_distances([(frame, frame_at[s["left"]], frame_at[s["right"]])
+                                              for s, (_, frame) in zip(specs, results)])
             for k, (s, (traj, frame)) in enumerate(zip(specs, results)):
                 ready[(s["left"], s["right"])] = dict(fract=s["fract"], traj=traj, frame=frame,
-                                                      sl=sims[2 * k], sr=sims[2 * k + 1])
+                                                      sl=sims[k][0], sr=sims[k][1])
             self.guidance_scale = self.dh.guidance_scale = specs[-1]["guidance"]
             self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
         self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
+
+    def _gap_child_distances(self, triples):
+        """[(child frame, left neighbour, right neighbour)] -> [(d_left, d_right)].  Under a farm the perceptual
+        metric is SHARDED: every rank measures only the children it owns (features of the frames involved are
+        computed on demand and cached) and the scalars are all-gathered, so all ranks decide on bit-identical
+        numbers."""
+        if not self._farm_on():
+            flat = []
+            for child, left, right in triples:
+                flat += [(child, left), (child, right)]
+            sims = self._frame_distances(flat)
+            return [(sims[2 * k], sims[2 * k + 1]) for k in range(len(triples))]
+        own = self.farm.my_indices(len(triples))
+        flat = []
+        for k in own:
+            child, left, right = triples[k]
+            flat += [(child, left), (child, right)]
+        sims = self._frame_distances(flat)
+        got = self.farm.exchange_scalars([(sims[2 * j], sims[2 * j + 1]) for j in range(len(own))], len(triples))
+        return [(g[0], g[1]) for g in got]
+
+    def _latent_chw(self):
+        return (int(self.dh.pipe.unet.config.in_channels), int(self.dh.height_latent), int(self.dh.width_latent))
 
     def _frame_distances(self, pairs):
         pipe = self.dh.pipe
@@ -535,22 +605,34 @@ class BlendingEngine:
             return pipe.native_frame_distances(pairs) if pairs else []
         return [self.get_lpips_similarity(a, b) for a, b in pairs]
 
-    def _evaluate_specs(self, specs, idx_injection):
+    def _evaluate_specs(self, specs, idx_injection, only=None):
         """(trajectory, decoded frame) for every speculated gap child.  Native pipe: ONE batched
-        denoising run + one batched decode.  Generic pipe: spec by spec through the diffusers-style API."""
+        denoising run + one batched decode.  Generic pipe: spec by spec through the diffusers-style API.
+        ``only``: indices of the specs this rank evaluates (farm); the others are skipped, but a shared noise
+        stream is advanced past them so that it stays aligned across ranks."""
         if not specs:
             return []
         pipe = self.dh.pipe
+        chosen = list(range(len(specs))) if only is None else list(only)
         if _is_native(pipe):
+            if not chosen:
+                if getattr(pipe.scheduler, "ancestral", False):
+                    self._skip_noise_draws(len(specs) * (self.num_inference_steps - idx_injection))
+                return []
+            sel = [specs[k] for k in chosen]
             trajs = pipe.native_run_diffusion_batch(
-                [s["cond"] for s in specs], [s["mixed"][idx_injection - 1] for s in specs],
-                idx_injection, [s["mixed"] for s in specs], [s["coeffs"] for s in specs],
+                [s["cond"] for s in sel], [s["mixed"][idx_injection - 1] for s in sel],
+                idx_injection, [s["mixed"] for s in sel], [s["coeffs"] for s in sel],
                 num_inference_steps=self.num_inference_steps,
-                guidance_scales=[s["guidance"] for s in specs])
+                guidance_scales=[s["guidance"] for s in sel],
+                noise_slots=None if only is None else (len(specs), chosen))
             frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil")
             return list(zip(trajs, frames))
         out = []
-        for s in specs:
+        for k, s in enumerate(specs):
+            if k not in chosen:
+                self._skip_noise_draws(self.num_inference_steps - idx_injection)
+                continue
             self.guidance_scale = self.dh.guidance_scale = s["guidance"]
             traj = self.run_diffusion([s["cond"]], latents_start=s["mixed"][idx_injection - 1], idx_start=idx_injection,
                                       list_latents_mixing=s["mixed"], mixing_coeffs=s["coeffs"])
@@ -572,23 +654,33 @@ class BlendingEngine:
             return DeviceImage(u8)
         return Image.fromarray(u8.cpu().numpy())
 
-    def _anchors_distributed(self):
-        """Farm mode: anchor 1 on rank 0, anchor 2 on rank 1 (when it is not crossfed from anchor 1),
-        then every rank receives both latent stacks (C1 of SURVEY.md §8e)."""
+    def _anchors_distributed(self, keep1=False, keep2=False):
+        """Farm mode without the fused wavefront (generic pipes, crossfed or recycled anchors): every anchor that is
+        not recycled is denoised on ONE owner rank and broadcast (C1 of SURVEY.md §8e), so all ranks continue from
+        bit-identical stacks whatever their local RNG state is.  Anchor 1 lives on rank 0; anchor 2 on rank 1 when it
+        can run concurrently (anchor 1 is being computed and is not crossfed into it), else on rank 0.  A recycled
+        anchor is already identical everywhere (it was exchanged, or computed from exchanged data, last transition).
+        Ranks that do not compute an anchor advance a shared noise stream past its draws."""
         farm, steps = self.farm, self.num_inference_steps
         independent = self.branch1_crossfeed_power == 0.0
-        owner2 = 1 % farm.world if independent else 0
-        first = last = None
-        if farm.rank == 0:
-            first = self.compute_latents1()
-        elif independent and farm.rank == owner2:
-            self._skip_noise_draws(steps)            # keep a shared noise tape aligned with a serial run
-        if farm.rank == owner2:
-            if not independent:
-                self.tree_latents[0] = first
-            last = self.compute_latents2()
-        first = self._on_pipe_device(farm.share_trajectory(first, 0, steps))
-        last = self._on_pipe_device(farm.share_trajectory(last, owner2, steps))
+        shape = (1,) + self._latent_chw()
+        ancestral = bool(getattr(getattr(self.dh.pipe, "scheduler", None), "ancestral", False))
+        first = self.tree_latents[0] if keep1 else None
+        if not keep1:
+            if farm.rank == 0:
+                first = self.compute_latents1()
+            elif ancestral:
+                self._skip_noise_draws(steps)
+            first = self._on_pipe_device(farm.share_trajectory(first if farm.rank == 0 else None, 0, steps, shape))
+            self.tree_latents[0] = first
+        last = self.tree_latents[-1] if keep2 else None
+        if not keep2:
+            owner2 = 1 % farm.world if (independent and not keep1) else 0
+            if farm.rank == owner2:
+                last = self.compute_latents2()
+            elif ancestral:
+                self._skip_noise_draws(steps)
+            last = self._on_pipe_device(farm.share_trajectory(last if farm.rank == owner2 else None, owner2, steps, shape))
         self.tree_latents[0], self.tree_latents[-1] = first, last
         return first, last
 

@@ -3,18 +3,23 @@
 One process per GPU (``torchrun``), ``torch.distributed`` with backend ``nccl`` (= RCCL over xGMI
 on MI355X) or ``gloo`` (CPU tests).  The program is SPMD: every rank runs the same
 ``BlendingEngine`` and takes the same decisions from the same data, so no control messages exist.
-Only two kinds of payload ever move:
+What moves:
 
-* C1  the two anchor latent stacks, from the rank that denoised them to everybody
-      (``share_trajectory``: one all-gather of a [steps,4,L,L] fp16 stack, 128 KiB at 512^2);
-* C2/C3  per speculative round, the branches each rank evaluated: latent stack from the injection
-      step on, decoded uint8 frame, and the two neighbour distances (``exchange_branches``: three
-      all-gathers of fixed-size slots).
+* nothing for the anchors on the native fast path: the two anchor trajectories are a B = 2 batch that
+  every rank computes itself inside the same wavefront as its share of mid branches (27 ms of
+  redundant work buys away a broadcast, an idle phase on N-2 ranks and a synchronisation point);
+* C1 (generic pipes, recycled / crossfed anchors): ``share_trajectory`` — ONE ``broadcast`` of the
+  [steps,4,L,L] fp16 stack from the rank that denoised it (128 KiB at 512^2);
+* C2/C3 per speculative round: ``exchange_branches`` — ONE all-gather of a packed byte slot per branch
+  (latent stack from the injection step on + decoded uint8 frame; 832 KiB at 512^2) and
+  ``exchange_scalars`` — ONE all-gather of the two float64 neighbour distances each rank measured for
+  the branches it owns (LPIPS is sharded, its features are computed on demand and cached per frame).
 
-There is no all-reduce on this path and every message is small (<= a few MiB), i.e. latency- not
-bandwidth-bound on xGMI: one collective per payload kind per round, never per branch.
-A branch is a pure function of (parent stacks, conditionings, fraction), so any rank may evaluate
-any branch and a lost branch can simply be recomputed.
+There is no all-reduce on this path and every message is small (<= a few MiB per rank), i.e. latency-
+not bandwidth-bound on xGMI: two collectives per round, never one per branch.  A branch is a pure
+function of (parent stacks, conditionings, fraction), so any rank may evaluate any branch.
+``check_consistent`` lets the engine verify (cheaply, once per transition) that every rank derived
+the same branching plan before any collective whose shape depends on it is issued.
 """
 from __future__ import annotations
 
@@ -44,52 +49,97 @@ class BranchFarm:
         self.collectives += 1
         return out
 
+    def _broadcast(self, t: torch.Tensor, src: int) -> torch.Tensor:
+        t = t.to(self.device).contiguous()
+        dist.broadcast(t, src=src if self.group is None else dist.get_global_rank(self.group, src), group=self.group)
+        self.bytes_moved += t.numel() * t.element_size()
+        self.collectives += 1
+        return t
+
+    def owner_of(self, index: int) -> int:
+        """Round-robin ownership of the ``index``-th branch of a round."""
+        return index % self.world
+
+    def my_indices(self, n_total: int) -> List[int]:
+        return list(range(self.rank, n_total, self.world))
+
+    # -- plan agreement -------------------------------------------------------------------------
+    def check_consistent(self, values: Sequence[float], what: str = "branching plan") -> None:
+        """Every rank contributes the same vector or the run stops HERE with a clear error instead of hanging in
+        a later collective with mismatched shapes (e.g. a time-budget plan derived from rank-local timings)."""
+        v = torch.tensor([float(x) for x in values], dtype=torch.float64)
+        got = self._all_gather(v)
+        for r, other in enumerate(got):
+            if other.shape != got[0].shape or not torch.equal(other.cpu(), got[0].cpu()):
+                raise RuntimeError(f"BranchFarm: rank {r} derived a different {what} than rank 0: "
+                                   f"{other.tolist()} vs {got[0].tolist()}")
+
+    def broadcast_floats(self, values: Sequence[float], src: int = 0) -> List[float]:
+        """Rank ``src``'s values on every rank (timings that feed the planner, noise seeds ...)."""
+        t = torch.tensor([float(x) for x in values], dtype=torch.float64)
+        return [float(x) for x in self._broadcast(t, src).cpu().tolist()]
+
     # -- C1: anchors --------------------------------------------------------------------------
-    def share_trajectory(self, traj: Optional[Sequence[torch.Tensor]], owner: int, steps: int, like=None):
-        """Every rank gets the owner's full trajectory (list of ``steps`` latents)."""
-        meta = torch.zeros(5, dtype=torch.int64)
-        if self.rank == owner:
-            z = traj[0]
-            meta = torch.tensor([z.shape[0], z.shape[1], z.shape[2], z.shape[3], 0], dtype=torch.int64)
-        metas = self._all_gather(meta)
-        b, c, h, w, _ = [int(v) for v in metas[owner].tolist()]
+    def share_trajectory(self, traj: Optional[Sequence[torch.Tensor]], owner: int, steps: int,
+                         shape: Optional[Tuple[int, int, int, int]] = None):
+        """Every rank gets the owner's full trajectory (list of ``steps`` latents): one broadcast.
+        ``shape`` = (b, c, h, w) of one latent (every rank knows it from its own pipe)."""
+        if shape is None:
+            meta = torch.zeros(4, dtype=torch.int64)
+            if self.rank == owner:
+                meta = torch.tensor(list(traj[0].shape), dtype=torch.int64)
+            shape = tuple(int(v) for v in self._broadcast(meta, owner).cpu().tolist())
+        b, c, h, w = shape
         if self.rank == owner:
             stack = torch.stack([t.reshape(b, c, h, w) for t in traj]).to(self.device, torch.float16)
         else:
             stack = torch.zeros(steps, b, c, h, w, dtype=torch.float16, device=self.device)
-        got = self._all_gather(stack)[owner]
+        got = self._broadcast(stack, owner)
         return [got[i].clone() for i in range(steps)]
 
     # -- C2/C3: one speculative round ------------------------------------------------------------
-    def exchange_branches(self, mine: List[Tuple[list, object, float, float]], n_total: int, active_steps: int,
-                          total_steps: int, make_frame: Callable[[torch.Tensor], object]):
-        """``mine``: results (trajectory, frame, sim_left, sim_right) of specs rank, rank+world, ...
-        Returns the results of ALL ``n_total`` specs, in spec order, on every rank.  Trajectories
-        travel from the injection step on (``active_steps`` latents) and are re-padded with ``None``."""
+    def exchange_branches(self, mine: List[Tuple[list, object]], n_total: int, active_steps: int, total_steps: int,
+                          make_frame: Callable[[torch.Tensor], object], lat_shape: Tuple[int, int, int],
+                          frame_hw: Tuple[int, int]):
+        """``mine``: (trajectory, frame) of the branches ``my_indices(n_total)`` in that order.
+        Returns (trajectory, frame) of ALL ``n_total`` branches, in branch order, on every rank.
+        One all-gather of a packed uint8 slot per branch: [active_steps latents fp16 | frame u8]; trajectories
+        travel from the injection step on and are re-padded with ``None``.  The payload shapes are arguments
+        (every rank knows them from its own pipe), so a rank that owns no branch this round needs no metadata."""
+        c, h, w = lat_shape
+        fh, fw = frame_hw
+        lat_bytes = active_steps * c * h * w * 2
+        frm_bytes = fh * fw * 3
+        slot = (lat_bytes + frm_bytes + 15) // 16 * 16
         slots = (n_total + self.world - 1) // self.world
-        shape = torch.zeros(6, dtype=torch.int64)          # every rank learns the payload shapes
-        if mine:
-            z, f = mine[0][0][-1], self._frame_u8(mine[0][1])
-            shape = torch.tensor([z.shape[-3], z.shape[-2], z.shape[-1], f.shape[0], f.shape[1], 1], dtype=torch.int64)
-        ref = next(s for s in self._all_gather(shape) if int(s[5]) == 1)
-        c, h, w, fh, fw, _ = [int(v) for v in ref.tolist()]
-        lat = torch.zeros(slots, active_steps, c, h, w, dtype=torch.float16, device=self.device)
-        frm = torch.zeros(slots, fh, fw, 3, dtype=torch.uint8, device=self.device)
-        sim = torch.zeros(slots, 2, dtype=torch.float64, device=self.device)
-        for k, (traj, frame, sl, sr) in enumerate(mine):
+        assert len(mine) == len(self.my_indices(n_total)), (len(mine), n_total, self.rank, self.world)
+        buf = torch.zeros(slots, slot, dtype=torch.uint8, device=self.device)
+        for k, (traj, frame) in enumerate(mine):
             live = [t for t in traj if t is not None]
             assert len(live) == active_steps, (len(live), active_steps)
-            lat[k] = torch.stack([t.reshape(c, h, w) for t in live]).to(self.device, torch.float16)
-            frm[k] = self._frame_u8(frame).to(self.device)
-            sim[k, 0], sim[k, 1] = float(sl), float(sr)
-        lats, frms, sims = self._all_gather(lat), self._all_gather(frm), self._all_gather(sim)
-        sims = [x.cpu() for x in sims]
+            lat = torch.stack([t.reshape(c, h, w) for t in live]).to(self.device, torch.float16).contiguous()
+            buf[k, :lat_bytes] = lat.view(torch.uint8).reshape(-1)
+            buf[k, lat_bytes:lat_bytes + frm_bytes] = self._frame_u8(frame).to(self.device).reshape(-1)
+        got = self._all_gather(buf)
         out = []
         for idx in range(n_total):
             r, k = idx % self.world, idx // self.world
-            traj = [None] * (total_steps - active_steps) + [lats[r][k, i].unsqueeze(0).clone() for i in range(active_steps)]
-            out.append((traj, make_frame(frms[r][k].clone()), float(sims[r][k, 0]), float(sims[r][k, 1])))
+            row = got[r][k]
+            lat = row[:lat_bytes].clone().view(torch.float16).view(active_steps, 1, c, h, w)
+            traj = [None] * (total_steps - active_steps) + [lat[i] for i in range(active_steps)]
+            frm = row[lat_bytes:lat_bytes + frm_bytes].clone().view(fh, fw, 3)
+            out.append((traj, make_frame(frm)))
         return out
+
+    def exchange_scalars(self, mine: Sequence[Sequence[float]], n_total: int, width: int = 2) -> List[List[float]]:
+        """``mine``: ``width`` float64 values for each of ``my_indices(n_total)``; returns the values of all
+        ``n_total`` branches in branch order, bit-identical on every rank (they are gathered, never recomputed)."""
+        slots = (n_total + self.world - 1) // self.world
+        t = torch.zeros(slots, width, dtype=torch.float64)
+        for k, vals in enumerate(mine):
+            t[k] = torch.tensor([float(v) for v in vals], dtype=torch.float64)
+        got = [g.cpu() for g in self._all_gather(t)]
+        return [[float(v) for v in got[idx % self.world][idx // self.world].tolist()] for idx in range(n_total)]
 
     @staticmethod
     def _frame_u8(frame) -> torch.Tensor:

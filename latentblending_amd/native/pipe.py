@@ -272,9 +272,13 @@ class StableDiffusionXLPipeline:
     @torch.no_grad()
     def native_run_diffusion_batch(self, conds: Sequence[tuple], starts: Sequence[torch.Tensor], idx_start: int,
                                    mixings: Sequence[Optional[list]], coeffs_list: Sequence[Sequence[float]],
-                                   num_inference_steps: int, guidance_scales: Sequence[float]):
+                                   num_inference_steps: int, guidance_scales: Sequence[float],
+                                   noise_slots: Optional[Tuple[int, Sequence[int]]] = None):
         """Denoise G branches in lock-step from ``idx_start``.  Returns per branch a list with one
-        entry per step (``None`` below ``idx_start``, else the [1,4,L,L] latent after that step)."""
+        entry per step (``None`` below ``idx_start``, else the [1,4,L,L] latent after that step).
+        ``noise_slots`` = (n_total, my_indices): these G branches are numbers ``my_indices`` of a round of
+        ``n_total`` branches evaluated by several ranks; ancestral noise is then drawn for all ``n_total`` in
+        order and only this rank's share is used, so a shared noise stream stays aligned across ranks."""
         G = len(conds)
         sched = self.scheduler
         if sched.num_inference_steps != num_inference_steps:
@@ -284,6 +288,7 @@ class StableDiffusionXLPipeline:
         wants = [self.uses_cfg(g) for g in guidance_scales]
         if any(wants) and not all(wants):
             out: List[Optional[list]] = [None] * G
+            assert noise_slots is None, "mixed CFG / non-CFG rounds are not supported under a farm"
             for flag in (False, True):
                 idx = [g for g in range(G) if wants[g] == flag]
                 part = self.native_run_diffusion_batch([conds[g] for g in idx], [starts[g] for g in idx], idx_start,
@@ -321,9 +326,10 @@ class StableDiffusionXLPipeline:
         noise_all = None
         if sched.ancestral and num_inference_steps > idx_start:
             shape1 = (1,) + tuple(latents.shape[1:])
+            n_draw, keep = (G, list(range(G))) if noise_slots is None else (int(noise_slots[0]), list(noise_slots[1]))
             per_branch = [torch.cat([sched.draw_noise(shape1, self.device)
-                                     for _ in range(idx_start, num_inference_steps)]) for _ in range(G)]
-            noise_all = torch.stack(per_branch, dim=1).contiguous()       # [steps, G, 4, L, L]
+                                     for _ in range(idx_start, num_inference_steps)]) for _ in range(n_draw)]
+            noise_all = torch.stack([per_branch[k] for k in keep], dim=1).contiguous()       # [steps, G, 4, L, L]
         for i in range(idx_start, num_inference_steps):
             if i > 0:
                 mix = [g for g in range(G) if coeffs_list[g][i] > 0]
@@ -355,7 +361,8 @@ class StableDiffusionXLPipeline:
     def native_run_wavefront(self, anchor_conds: Sequence[tuple], anchor_starts: Sequence[torch.Tensor],
                              mid_conds: Sequence[tuple], mid_fracts: Sequence[float],
                              mid_coeffs: Sequence[Sequence[float]], idx_injection: int, num_inference_steps: int,
-                             guidance_anchor: float, guidance_mids: Sequence[float]):
+                             guidance_anchor: float, guidance_mids: Sequence[float],
+                             noise_slots: Optional[Tuple[int, Sequence[int]]] = None):
         """Both anchors AND a set of mid branches whose parents are the anchors, in one wavefront.
 
         A mid branch at step i only needs the anchors' latents of step i-1 (its start latent and its
@@ -363,7 +370,9 @@ class StableDiffusionXLPipeline:
         of the reference), so from ``idx_injection`` on the anchors' step i and every mid branch's step
         i share ONE UNet batch of 2+G samples: 2 small + (steps-idx) large forwards instead of
         ``steps`` small + (steps-idx) large ones.  Arithmetic per sample is the same as in the
-        separate runs.  Returns (trajectory anchor 1, trajectory anchor 2, [mid trajectories])."""
+        separate runs.  Returns (trajectory anchor 1, trajectory anchor 2, [mid trajectories]).
+        ``noise_slots`` = (n_total, my_indices) as in ``native_run_diffusion_batch`` (farm: every rank runs both
+        anchors plus its own share of the round's mid branches)."""
         A, G = 2, len(mid_conds)
         sched, steps = self.scheduler, num_inference_steps
         if sched.num_inference_steps != steps:
@@ -404,8 +413,10 @@ class StableDiffusionXLPipeline:
         if sched.ancestral:       # sample-major draws: anchor 1, anchor 2, then every mid branch
             noise_a = torch.stack([torch.cat([sched.draw_noise(shape1, self.device) for _ in range(steps)])
                                    for _ in range(A)], dim=1)
-            noise_m = torch.stack([torch.cat([sched.draw_noise(shape1, self.device) for _ in range(idx_injection, steps)])
-                                   for _ in range(G)], dim=1) if G else None
+            n_draw, keep = (G, list(range(G))) if noise_slots is None else (int(noise_slots[0]), list(noise_slots[1]))
+            drawn = [torch.cat([sched.draw_noise(shape1, self.device) for _ in range(idx_injection, steps)])
+                     for _ in range(n_draw)]
+            noise_m = torch.stack([drawn[k] for k in keep], dim=1) if G else None
         lat_a = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in anchor_starts]).contiguous()
         lat_m = None
         traj_a = [[], []]

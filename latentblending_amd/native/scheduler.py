@@ -24,6 +24,20 @@ def _sigma_table() -> np.ndarray:
     return ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5
 
 
+class SeededDeviceNoise:
+    """Noise stream ``callable(shape) -> fp16 tensor`` from a device generator with an explicit seed: the same
+    seed gives the same stream on every rank of a branch farm (same GPU model, same torch build), which is what
+    lets ranks compute the anchor trajectories redundantly instead of exchanging them."""
+
+    def __init__(self, seed: int, device):
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
+
+    def __call__(self, shape):
+        return torch.randn(tuple(shape), generator=self.gen, device=self.device, dtype=torch.float16)
+
+
 class NativeEulerScheduler:
     order = 1
 

@@ -1,6 +1,8 @@
-"""World-size-2 `gloo` test of the branch farm on CPU: two ranks run the SPMD engine on the tiny
-oracle pipe, split every speculative round between them, and must both end with exactly the tree
-the sequential reference produced (tests/golden/tree.json: fractions, similarities, latents, frames)."""
+"""`gloo` tests of the branch farm on CPU: 2 / 3 ranks run the SPMD engine on the tiny oracle pipe, split every
+speculative round between them (unevenly at world 3), and must all end with exactly the tree the sequential
+reference produced (tests/golden/tree.json: fractions, similarities, latents, frames); chained transitions with a
+recycled anchor (swap_forward + recycle_img1) must equal the farm-less run; ranks holding different plans must
+fail loudly instead of hanging."""
 import hashlib
 import json
 import os
@@ -61,18 +63,105 @@ def _worker(rank, world, port, run, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("run", [0, 2])
-def test_branch_farm_world2_reproduces_sequential_tree(run, tmp_path):
+@pytest.mark.parametrize("run,world", [(0, 2), (2, 2), (0, 3)])
+def test_branch_farm_reproduces_sequential_tree(run, world, tmp_path):
+    """world 3 splits rounds of 4 branches 2 / 1 / 1 (and later rounds leave ranks without a branch)."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, run, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, run, str(tmp_path)), nprocs=world, join=True)
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "tree.json")))[run]
-    r0, r1 = [json.load(open(tmp_path / f"rank{r}.json")) for r in (0, 1)]
-    for r in (r0, r1):
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    for r in res:
         assert r["fracts"] == gold["tree_fracts"] and r["idx"] == gold["tree_idx_injection"]
         assert np.allclose(r["sims"], gold["tree_similarities"], rtol=2e-3)
         assert r["collectives"] > 0 and r["bytes"] > 0
-    # SPMD: both ranks hold bit-identical trees, latents and frames
-    assert r0["sims"] == r1["sims"] and r0["latent_sha"] == r1["latent_sha"] and r0["frame_sha"] == r1["frame_sha"]
-    # the work really was split: neither rank ran all UNet forwards of the sequential engine
-    assert r0["unet_calls"] < gold["unet_calls"] and r1["unet_calls"] < gold["unet_calls"]
+        # the work really was split: no rank ran all UNet forwards of the sequential engine
+        assert r["unet_calls"] < gold["unet_calls"]
+    # SPMD: all ranks hold bit-identical trees, latents and frames
+    for r in res[1:]:
+        assert r["sims"] == res[0]["sims"] and r["latent_sha"] == res[0]["latent_sha"] and r["frame_sha"] == res[0]["frame_sha"]
+
+
+def _chain_worker(rank, world, port, out_dir):
+    """Two chained transitions (example_multi_trans.py:39-58: swap_forward + recycle_img1) with ancestral noise from a
+    tape; world 1 = the farm-less engine in the same frontier mode."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    set_backend(R.TorchCpuBackend())
+    p = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+    np.random.seed(0)
+    farm = BranchFarm() if world > 1 else None
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=3, farm=farm)
+    be.set_dimensions((128, 128))
+    be.set_branching(nmb_max_branches=4)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+    p.noise.reset()
+    out = []
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    out.append({"fracts": [float(f) for f in be.tree_fracts], "sims": [float(s) for s in be.tree_similarities],
+                "frames": [int(np.asarray(i).astype(np.int64).sum()) for i in imgs]})
+    be.swap_forward()
+    be.set_prompt2("a forest in the fog")
+    imgs = be.run_transition(recycle_img1=True, fixed_seeds=[421, 999])
+    out.append({"fracts": [float(f) for f in be.tree_fracts], "sims": [float(s) for s in be.tree_similarities],
+                "frames": [int(np.asarray(i).astype(np.int64).sum()) for i in imgs],
+                "last_norm": float(be.tree_latents[-1][-1].float().norm())})
+    json.dump(out, open(os.path.join(out_dir, f"chain_rank{rank}_of{world}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_recycled_anchor_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_chain_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_chain_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    solo = json.load(open(tmp_path / "chain_rank0_of1.json"))
+    r0, r1 = [json.load(open(tmp_path / f"chain_rank{r}_of2.json")) for r in (0, 1)]
+    assert r0 == r1, "ranks diverged"                       # bit-identical on both ranks, both transitions
+    for t in (0, 1):
+        assert r0[t]["fracts"] == solo[t]["fracts"]
+        assert np.allclose(r0[t]["sims"], solo[t]["sims"], rtol=1e-5)
+        assert r0[t]["frames"] == solo[t]["frames"]
+    assert abs(r0[1]["last_norm"] - solo[1]["last_norm"]) <= 1e-3 * solo[1]["last_norm"]
+
+
+def _mismatch_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    set_backend(R.TorchCpuBackend())
+    p = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=2, farm=BranchFarm())
+    be.set_dimensions((128, 128))
+    be.set_branching(nmb_max_branches=3 + rank)             # ranks disagree about the plan
+    be.set_prompt1("a")
+    be.set_prompt2("b")
+    try:
+        be.run_transition(fixed_seeds=[1, 2])
+        msg = "no error"
+    except RuntimeError as exc:
+        msg = str(exc)
+    json.dump({"msg": msg}, open(os.path.join(out_dir, f"mismatch_rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_detects_diverging_plans(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_mismatch_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        msg = json.load(open(tmp_path / f"mismatch_rank{r}.json"))["msg"]
+        assert "different branching plan" in msg, msg
