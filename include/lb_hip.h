@@ -74,7 +74,13 @@ enum {
     LB_GEMM_GEGLU = 4,       /* W = [h rows | gate rows], C[M, N/2] = h * gelu(gate) */
     LB_GEMM_TRANS_OUT = 8,   /* store C^T: C[n*ldc + m] */
     LB_GEMM_SILU = 16,       /* SiLU after bias/residual */
-    LB_GEMM_RELU = 32        /* ReLU after bias/residual */
+    LB_GEMM_RELU = 32,       /* ReLU after bias/residual */
+    LB_GEMM_LN_A = 64        /* A is consumed through a LayerNorm over its K columns (K = the normalised width):
+                                C = LN(A) . Wt computed as rstd_m * (A . W'^T - mean_m * colsum) + bias with
+                                W' = W * gamma (folded by the caller), ln_colsum[n] = sum_k W'[n][k],
+                                bias[n] = b[n] + sum_k W[n][k] * beta[k]; the row statistics are accumulated from
+                                the A fragments inside the K loop (no LayerNorm launch, no normalised copy of A).
+                                Plain / GEGLU GEMMs of the direct-to-LDS family only, never split along K. */
 };
 
 typedef struct LbGemmParams {
@@ -103,6 +109,9 @@ typedef struct LbGemmParams {
      * KH = KW = 2, Hout = Hin, Wout = Win, pad is implied (1 - parity) and row m = (b, y, x) is
      * stored at pixel (2y + sc_py, 2x + sc_px) of the [B][2H][2W][ldc] output. */
     int scatter, sc_py, sc_px, reserved_;
+    const float* ln_colsum;  /* LB_GEMM_LN_A: [N] fp32 column sums of W' */
+    float ln_eps;            /* LB_GEMM_LN_A: LayerNorm epsilon */
+    int reserved2_;
 } LbGemmParams;
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);

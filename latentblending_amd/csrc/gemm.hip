@@ -438,7 +438,7 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
     const int bm = tile >= 4 ? 256 : (tile == 3 ? 64 : 128), bn = tile == 5 ? 256 : ((tile == 1 || tile == 4) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
-    if (!geglu && p.partial != nullptr) {
+    if (!geglu && p.partial != nullptr && !(p.flags & LB_GEMM_LN_A)) {     // (LN_A: a block must see whole rows of A)
         const int k_tiles = (p.K + BK - 1) / BK;
         if (g_force_splitk) splitk = g_force_splitk;
         else if (nblk <= 256) {
@@ -486,6 +486,11 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
                        "lb_gemm_f16: sub-pixel conv needs KH=KW=2, stride 1, Hout=Hin, no residual");
     } else {
         LB_REQUIRE(p.lda % 8 == 0, "lb_gemm_f16: lda must be a multiple of 8");
+    }
+    if (p.flags & LB_GEMM_LN_A) {
+        LB_REQUIRE(!p.conv && p.ln_colsum != nullptr && p.zero_page != nullptr && g_variant == 1,
+                   "lb_gemm_f16: LB_GEMM_LN_A needs a plain / GEGLU GEMM of the direct-to-LDS family with ln_colsum");
+        LB_REQUIRE(p.lda >= p.K && !(p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: LB_GEMM_LN_A normalises whole rows of A");
     }
     if (p.alpha == 0.f) p.alpha = 1.f;
     if (use_halo(p)) LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));

@@ -33,8 +33,26 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// Row statistics for a LayerNorm fused into the A operand (LB_GEMM_LN_A): the lane's fragment of K-half s holds 8
+// consecutive k-values of row (16 i + l16) for every i < TM; over the whole K loop the four lanes g = 0..3 of a row
+// see every column exactly once.  Sums run on the (idle) VALU as v_dot2_f32_f16: x.x and x.1 of two halves per
+// instruction, fp32 accumulation.
+typedef _Float16 lb_h2 __attribute__((ext_vector_type(2)));
+template <int TM>
+__device__ __forceinline__ void ln_accumulate(const f16x8 (&af)[TM], float (&sum)[TM], float (&sq)[TM]) {
+    const lb_h2 one2 = {(f16)1.f, (f16)1.f};
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const lb_h2 x = {af[i][2 * e], af[i][2 * e + 1]};
+            sum[i] = __builtin_amdgcn_fdot2(x, one2, sum[i], false);
+            sq[i] = __builtin_amdgcn_fdot2(x, x, sq[i], false);
+        }
+}
+
 // WMW = waves along M (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along N
-template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW>
+template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, bool LNA = false>
 __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmParams p) {
     constexpr int NT = WMW * 128;           // threads per block
     constexpr int RPI = NT / 8;             // tile rows covered by one round of wave instructions
@@ -180,6 +198,9 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ln_sum[TM], ln_sq[TM];            // LNA: running sum / sum of squares of this lane's k-slice of its rows
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ln_sum[i] = ln_sq[i] = 0.f;
 
     // operand fragments of K-half s of the tile in stage st
     auto read_frags = [&](int st, int s, f16x8 (&af)[TM], f16x8 (&wf)[TN]) {
@@ -230,6 +251,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 read_frags(st, s, af, wf);
+                if (LNA) ln_accumulate<TM>(af, ln_sum, ln_sq);
                 mma_rows(af, wf, 0, TM);
             }
         } else {
@@ -243,6 +265,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a0, w0, 0, HM);
             read_frags(st, 1, a1, w1);
+            if (LNA) ln_accumulate<TM>(a0, ln_sum, ln_sq);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int idx = 0; idx < NL; ++idx)
@@ -260,6 +283,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
             for (int idx = 0; idx < NL; ++idx)
                 if (idx * 4 / NL == 3) issue_one(idx, base, k_ok);
             advance_k();
+            if (LNA) ln_accumulate<TM>(a1, ln_sum, ln_sq);
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a1, w1, HM, TM);
         }
@@ -282,6 +306,26 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
         }
         return;
     }
+    if (LNA) {
+        // every lane ends with the statistics of its own TM output rows: fold the four k-slices (g = 0..3) of a row
+        LbLnRows<TM> ln;
+        const float inv_k = 1.f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float su = ln_sum[i], sq = ln_sq[i];
+            su += __shfl_xor(su, 16, LB_WAVE); sq += __shfl_xor(sq, 16, LB_WAVE);
+            su += __shfl_xor(su, 32, LB_WAVE); sq += __shfl_xor(sq, 32, LB_WAVE);
+            const float mean = su * inv_k;
+            const float var = fmaxf(sq * inv_k - mean * mean, 0.f);
+            ln.mean[i] = mean;
+            ln.rstd[i] = rsqrtf(var + p.ln_eps);
+        }
+        const int row0 = m0 + wave_m * WROWS + l16;
+        lb_gemm_tile_epilogue_rows_ln<TM, TN, GEGLU, true>(p, acc, [row0](int i) { return row0 + i * 16; },
+                                                           n0 + wave_n * (BN / 2) + 4 * g,
+                                                           n0 + wave_n * (BN / 64) * 16 + 4 * g, &ln);
+        return;
+    }
     lb_gemm_tile_epilogue<TM, TN, GEGLU>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
                                          n0 + wave_n * (BN / 64) * 16 + 4 * g);
 }
@@ -291,8 +335,11 @@ static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t str
     const size_t smem = (size_t)S * (BM + BN) * BK * sizeof(f16);
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
     const dim3 block(WMW * 128);
+    const bool lna = (p.flags & LB_GEMM_LN_A) != 0;
     if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>), grid, block, smem, stream, p);
+    else if (geglu && lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, true>), grid, block, smem, stream, p);
     else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>), grid, block, smem, stream, p);
+    else if (lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, true>), grid, block, smem, stream, p);
     else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW>), grid, block, smem, stream, p);
     return 0;
 }
@@ -306,6 +353,10 @@ static void allow_lds() {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
 }
 

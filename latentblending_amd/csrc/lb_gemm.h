@@ -79,11 +79,14 @@ __device__ __forceinline__ void lb_gemm_write4(const LbGemmParams& p, long crow,
     }
 }
 
+// Row statistics of a fused LayerNorm (LB_GEMM_LN_A): mean / rstd of the lane's TM output rows.
+template <int TM> struct LbLnRows { float mean[TM], rstd[TM]; };
+
 // RowFn: i -> global output row of the lane's i-th 16-row group (row0 + 16 i for the GEMM kernels; the pixel
 // index of a 2-D spatial tile for the halo conv kernel).
-template <int TM, int TN, bool GEGLU, typename RowFn>
-__device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
-                                                           RowFn row_of, int col0, int gcol0) {
+template <int TM, int TN, bool GEGLU, bool LNA, typename RowFn>
+__device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
+                                                           RowFn row_of, int col0, int gcol0, const LbLnRows<TM>* ln) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (GEGLU) {
         constexpr int TP = TN / 2 > 0 ? TN / 2 : 1;
@@ -104,11 +107,21 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p
             for (int jp = 0; jp < TP; ++jp) {
                 const int n = gcol0 + jp * 16;
                 if (n >= half) continue;
+                f32x4 ch = zero4, cg = zero4;       // (LN_A column sums: re-read per row, L1 hits, no registers held)
+                if (LNA) {
+                    ch = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+                    cg = *reinterpret_cast<const f32x4*>(p.ln_colsum + half + n);
+                }
                 f16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float h = acc[i][2 * jp][r] * p.alpha + bh[jp][r];
-                    const float gt = acc[i][(2 * jp + 1) % TN][r] * p.alpha + bg[jp][r];
+                    float ah = acc[i][2 * jp][r], ag = acc[i][(2 * jp + 1) % TN][r];
+                    if (LNA) {
+                        ah = (ah - ln->mean[i] * ch[r]) * ln->rstd[i];
+                        ag = (ag - ln->mean[i] * cg[r]) * ln->rstd[i];
+                    }
+                    const float h = ah * p.alpha + bh[jp][r];
+                    const float gt = ag * p.alpha + bg[jp][r];
                     o[r] = (f16)(h * lb_gelu_erf(gt));
                 }
                 *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) = o;
@@ -168,8 +181,14 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p
             const int n = col0 + j * 16;
             if (!m_ok || n >= p.N) continue;
             float o[4];
+            f32x4 cs = zero4;
+            if (LNA) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[i][j][r] * p.alpha + add[j][r];
+            for (int r = 0; r < 4; ++r) {
+                float a = acc[i][j][r];
+                if (LNA) a = (a - ln->mean[i] * cs[r]) * ln->rstd[i];
+                o[r] = a * p.alpha + add[j][r];
+            }
             if (p.flags & LB_GEMM_SILU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = lb_silu(o[r]);
@@ -181,6 +200,12 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p
             lb_gemm_write4(p, crow, m, n, o);
         }
     }
+}
+
+template <int TM, int TN, bool GEGLU, typename RowFn>
+__device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
+                                                           RowFn row_of, int col0, int gcol0) {
+    lb_gemm_tile_epilogue_rows_ln<TM, TN, GEGLU, false>(p, acc, row_of, col0, gcol0, (const LbLnRows<TM>*)nullptr);
 }
 
 template <int TM, int TN, bool GEGLU>

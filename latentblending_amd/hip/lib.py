@@ -32,6 +32,7 @@ class LbGemmParams(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
         ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int),
     ]
 
 
@@ -44,7 +45,7 @@ class LbAttnParams(C.Structure):
     ]
 
 
-GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU = 1, 2, 4, 8, 16, 32
+GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU, GEMM_LN_A = 1, 2, 4, 8, 16, 32, 64
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 

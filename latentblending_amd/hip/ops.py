@@ -154,9 +154,10 @@ def subpixel_upsample_weights(w: torch.Tensor, cin_pad: Optional[int] = None):
 
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          flags: int = 0, alpha: float = 1.0, out: Optional[torch.Tensor] = None, splitk_ws: bool = True,
-         conv: Optional[dict] = None, M: Optional[int] = None) -> torch.Tensor:
+         conv: Optional[dict] = None, M: Optional[int] = None, ln=None) -> torch.Tensor:
     """C = epilogue(A . W^T).  A: [M, K] fp16 (or NHWC [B,H,W,C] with ``conv``), W: [N, K] fp16.
-    ``conv``: dict(KH, KW, stride, pad, ups) for an implicit-GEMM convolution."""
+    ``conv``: dict(KH, KW, stride, pad, ups) for an implicit-GEMM convolution.
+    ``ln`` = (colsum [N] fp32, eps): LayerNorm over A's columns folded into the GEMM (see ``fold_layernorm``)."""
     p = LbGemmParams()
     N, K = W.shape
     dev = A.device
@@ -195,10 +196,13 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     if rowvec is not None:
         p.ld_rowvec, p.rows_per_batch = rowvec.stride(0), rows_per_batch
     p.alpha, p.flags = alpha, flags
-    zp = torch.zeros(64, dtype=torch.uint8, device=dev)
+    zp = zero_page(dev)
     p.zero_page = zp.data_ptr()
+    if ln is not None:
+        p.flags |= lib.GEMM_LN_A
+        p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
     ws = None
-    if splitk_ws and not (flags & lib.GEMM_GEGLU):
+    if splitk_ws and not (flags & lib.GEMM_GEGLU) and ln is None:
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)
         p.partial = ws.data_ptr()
     if conv is not None and conv.get("halo"):         # experimental halo-tile 3x3 kernel (csrc/conv3_halo.hip)
@@ -206,6 +210,15 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     else:
         api.lb_gemm_f16(C.byref(p), stream_ptr())
     return out
+
+
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """(W', colsum, b') for ``gemm(..., ln=(colsum, eps))``: LN(x) W^T + b = rstd (x W'^T - mean colsum) + b'."""
+    wf = (w.double() * gamma.double()[None, :]).to(F16)
+    b2 = w.double() @ beta.double()
+    if bias is not None:
+        b2 = b2 + bias.double()
+    return wf, wf.double().sum(dim=1).to(F32), b2.to(F32)
 
 
 # ------------------------------------------------------------------------------ norms ------

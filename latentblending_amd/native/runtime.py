@@ -164,7 +164,10 @@ class Emitter:
     def gemm(self, A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, bias=None,
              residual=None, rowvec=None, rows_per_batch: int = 0, flags: int = 0, alpha: float = 1.0,
              lda: Optional[int] = None, ldc: Optional[int] = None, ldr: Optional[int] = None,
-             ld_rowvec: Optional[int] = None, conv: Optional[dict] = None, splitk: bool = True):
+             ld_rowvec: Optional[int] = None, conv: Optional[dict] = None, splitk: bool = True,
+             ln: Optional[Tuple[torch.Tensor, float]] = None):
+        """``ln`` = (colsum [N] fp32, eps): A is consumed through a LayerNorm folded into this GEMM (LB_GEMM_LN_A; W and
+        bias must already carry gamma / beta, see ``NativeUNet._ln_linear``)."""
         p = LbGemmParams()
         N, K = W.shape
         p.A, p.W, p.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
@@ -185,7 +188,10 @@ class Emitter:
             p.ld_rowvec, p.rows_per_batch = ld_rowvec if ld_rowvec is not None else N, rows_per_batch
         p.alpha, p.flags = alpha, flags
         p.zero_page = self.zero_page.data_ptr()
-        if splitk and not (flags & lib.GEMM_GEGLU):
+        if ln is not None:
+            p.flags |= lib.GEMM_LN_A
+            p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
+        if splitk and not (flags & lib.GEMM_GEGLU) and ln is None:
             p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())
         self.gemm_log.append({"M": M, "N": N, "K": K, "flops": 2.0 * M * N * K, "conv": conv is not None,

@@ -61,9 +61,14 @@ def _pad(n: int, m: int) -> int:
 
 
 class NativeUNet:
-    def __init__(self, cfg: UNetConfig, provider, device="cuda"):
+    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm: bool = True):
+        """``fuse_layernorm``: the three LayerNorms of every transformer block are folded into the GEMMs that consume
+        them (no LayerNorm launch, no normalised copy of the hidden state); False keeps separate LayerNorm launches
+        (A/B studies, and the only form the register-ring GEMM variant supports)."""
         assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
         self.cfg, self.device = cfg, torch.device(device)
+        self.fuse_layernorm = bool(fuse_layernorm)
+        self.keep_ln_weights = not self.fuse_layernorm
         self.w: Dict[str, torch.Tensor] = {}
         self.temb_slices: Dict[str, Tuple[int, int]] = {}      # resnet -> (offset, cout) in the fused projection
         self.ctx_slices: Dict[str, Tuple[int, int]] = {}       # transformer block -> (offset, C) in fused ctx K / V
@@ -99,9 +104,25 @@ class NativeUNet:
             self.w[f"{name}.weight.sub{py}{px}"] = k.to(self.device)
         self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
 
-    def _norm(self, pv, name, c):
-        self.w[name + ".weight"] = self._dev(pv.norm_weight(name + ".weight", c), F32)
-        self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
+    def _norm(self, pv, name, c, keep_host=False):
+        g, b = pv.norm_weight(name + ".weight", c), pv.bias(name + ".bias", c)
+        if not keep_host:
+            self.w[name + ".weight"] = self._dev(g, F32)
+            self.w[name + ".bias"] = self._dev(b, F32)
+        return g, b
+
+    def _ln_linear(self, pv, norm_name, key, w: torch.Tensor, bias: Optional[torch.Tensor], c: int):
+        """LayerNorm folded into the Linear that consumes it (``LB_GEMM_LN_A``): y = LN(x) W^T + b becomes
+        rstd * (x W'^T - mean * colsum) + b' with W' = W diag(gamma) (rounded to fp16: the MFMA operand),
+        colsum[n] = sum_k W'[n][k] (of the ROUNDED values) and b' = b + W beta.  ``key`` names the packed tensors."""
+        g, beta = self._norm(pv, norm_name, c, keep_host=not self.keep_ln_weights)
+        wf = (w.double() * g.double()[None, :]).to(torch.float16)
+        self.w[key + ".weight"] = wf.to(self.device).contiguous()
+        self.w[key + ".colsum"] = self._dev(wf.double().sum(dim=1), F32)
+        b2 = w.double() @ beta.double()
+        if bias is not None:
+            b2 = b2 + bias.double()
+        self.w[key + ".bias"] = self._dev(b2, F32)
 
     def _resnet(self, pv, p, cin, cout, temb_acc):
         T = self.cfg.time_embed_dim
@@ -127,14 +148,16 @@ class NativeUNet:
         self._linear(pv, p + ".proj_in", c, c)
         for d in range(depth):
             b = f"{p}.transformer_blocks.{d}"
-            self._norm(pv, b + ".norm1", c)
             q = self._linear(pv, b + ".attn1.to_q", c, c, bias=False, keep_host=True)
             k = self._linear(pv, b + ".attn1.to_k", c, c, bias=False, keep_host=True)
             v = self._linear(pv, b + ".attn1.to_v", c, c, bias=False, keep_host=True)
-            self.w[b + ".attn1.qkv"] = self._dev(torch.cat([q, k, v], 0), F16)      # one [3C, C] projection
+            qkv = torch.cat([q, k, v], 0)                                             # one [3C, C] projection
+            if self.keep_ln_weights:
+                self.w[b + ".attn1.qkv"] = self._dev(qkv, F16)
+            self._ln_linear(pv, b + ".norm1", b + ".attn1.qkv_ln", qkv, None, c)
             self._linear(pv, b + ".attn1.to_out.0", c, c, gain=0.5)
-            self._norm(pv, b + ".norm2", c)
-            self._linear(pv, b + ".attn2.to_q", c, c, bias=False)
+            q2 = self._linear(pv, b + ".attn2.to_q", c, c, bias=False, keep_host=not self.keep_ln_weights)
+            self._ln_linear(pv, b + ".norm2", b + ".attn2.to_q_ln", q2, None, c)
             ck = self._linear(pv, b + ".attn2.to_k", X, c, bias=False, keep_host=True)
             cv = self._linear(pv, b + ".attn2.to_v", X, c, bias=False, keep_host=True)
             self.ctx_slices[b] = (ctx_acc["n"], c)
@@ -142,8 +165,9 @@ class NativeUNet:
             ctx_acc["v"].append(cv)
             ctx_acc["n"] += c
             self._linear(pv, b + ".attn2.to_out.0", c, c, gain=0.5)
-            self._norm(pv, b + ".norm3", c)
-            self._linear(pv, b + ".ff.net.0.proj", c, 8 * c)
+            ff = self._linear(pv, b + ".ff.net.0.proj", c, 8 * c, keep_host=not self.keep_ln_weights)
+            ffb = pv.bias(b + ".ff.net.0.proj.bias", 8 * c)                   # (same seeded tensor _linear stored)
+            self._ln_linear(pv, b + ".norm3", b + ".ff.net.0.proj_ln", ff, ffb, c)
             self._linear(pv, b + ".ff.net.2", 4 * c, c, gain=0.5)
         self._linear(pv, p + ".proj_out", c, c, gain=0.5)
 
@@ -306,11 +330,16 @@ class UNetProgram:
         for d in range(depth):
             b = f"{p}.transformer_blocks.{d}"
             # --- self attention ---
-            ln = ar.alloc((M, c))
-            em.layernorm(h, ln, w[b + ".norm1.weight"], w[b + ".norm1.bias"], M=M, C_=c)
+            fuse = self.net.fuse_layernorm
             qkv = ar.alloc((M, 3 * c))
-            em.gemm(ln, w[b + ".attn1.qkv"], qkv, M=M)                  # Q | K | V in one launch
-            ar.release(ln)
+            if fuse:        # LayerNorm folded into the projection: statistics from the A fragments, affine in the epilogue
+                em.gemm(h, w[b + ".attn1.qkv_ln.weight"], qkv, M=M, bias=w[b + ".attn1.qkv_ln.bias"],
+                        ln=(w[b + ".attn1.qkv_ln.colsum"], 1e-5))
+            else:
+                ln = ar.alloc((M, c))
+                em.layernorm(h, ln, w[b + ".norm1.weight"], w[b + ".norm1.bias"], M=M, C_=c)
+                em.gemm(ln, w[b + ".attn1.qkv"], qkv, M=M)              # Q | K | V in one launch
+                ar.release(ln)
             a = ar.alloc((M, c))
             em.attention(qkv.data_ptr(), qkv.data_ptr() + c * 2, qkv.data_ptr() + 2 * c * 2, a, B=B, H=heads, Sq=S,
                          Skv=S, valid=S, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c)
@@ -318,11 +347,15 @@ class UNetProgram:
             em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h)
             ar.release(a)
             # --- cross attention (K / V^T of the text context come from the conditioning program) ---
-            ln = ar.alloc((M, c))
-            em.layernorm(h, ln, w[b + ".norm2.weight"], w[b + ".norm2.bias"], M=M, C_=c)
             q = ar.alloc((M, c))
-            em.gemm(ln, w[b + ".attn2.to_q.weight"], q, M=M)
-            ar.release(ln)
+            if fuse:
+                em.gemm(h, w[b + ".attn2.to_q_ln.weight"], q, M=M, bias=w[b + ".attn2.to_q_ln.bias"],
+                        ln=(w[b + ".attn2.to_q_ln.colsum"], 1e-5))
+            else:
+                ln = ar.alloc((M, c))
+                em.layernorm(h, ln, w[b + ".norm2.weight"], w[b + ".norm2.bias"], M=M, C_=c)
+                em.gemm(ln, w[b + ".attn2.to_q.weight"], q, M=M)
+                ar.release(ln)
             off, _ = self.net.ctx_slices[b]
             a = ar.alloc((M, c))
             em.attention(q.data_ptr(), self.ctx_kv.data_ptr() + off * 2,
@@ -332,12 +365,16 @@ class UNetProgram:
             em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h)
             ar.release(a)
             # --- GEGLU feed-forward ---
-            ln = ar.alloc((M, c))
-            em.layernorm(h, ln, w[b + ".norm3.weight"], w[b + ".norm3.bias"], M=M, C_=c)
             ff = ar.alloc((M, 4 * c))
-            em.gemm(ln, w[b + ".ff.net.0.proj.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj.bias"],
-                    flags=lib.GEMM_GEGLU)
-            ar.release(ln)
+            if fuse:
+                em.gemm(h, w[b + ".ff.net.0.proj_ln.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj_ln.bias"],
+                        flags=lib.GEMM_GEGLU, ln=(w[b + ".ff.net.0.proj_ln.colsum"], 1e-5))
+            else:
+                ln = ar.alloc((M, c))
+                em.layernorm(h, ln, w[b + ".norm3.weight"], w[b + ".norm3.bias"], M=M, C_=c)
+                em.gemm(ln, w[b + ".ff.net.0.proj.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj.bias"],
+                        flags=lib.GEMM_GEGLU)
+                ar.release(ln)
             em.gemm(ff, w[b + ".ff.net.2.weight"], h, M=M, bias=w[b + ".ff.net.2.bias"], residual=h)
             ar.release(ff)
         out = ar.alloc((B, H, W, c))

@@ -373,6 +373,35 @@ def test_layernorm(shape, results_log):
     check_close(results_log, f"layernorm_{M}_{C}", got, ref, floor=2e-3)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("case", [(512, 1280, 1280, False), (4352, 3840, 1280, False), (1024, 5120, 640, True),
+                                  (4352, 10240, 1280, True), (300, 192, 64, False)])
+def test_gemm_layernorm_fused(case, tile, results_log):
+    """LB_GEMM_LN_A: LayerNorm folded into the consuming GEMM (row statistics from the A fragments, affine fix in the
+    epilogue) vs torch LayerNorm -> Linear (-> GEGLU) in fp32, on rows with a large common offset (mean >> std is the
+    hard case of the E[x^2] - E[x]^2 form) and non-trivial gamma / beta."""
+    o, l = ops(), lib()
+    M, N, K, geglu = case
+    x = rnd(M, K, seed=81) * 1.5 + rnd(M, 1, seed=82) * 4.0          # per-row offsets up to ~3 sigma of the row spread
+    w = rnd(N, K, seed=83, scale=K ** -0.5)
+    b = rnd(N, seed=84, dtype=torch.float32)
+    gamma = 1.0 + 0.2 * rnd(K, seed=85, dtype=torch.float32)
+    beta = 0.1 * rnd(K, seed=86, dtype=torch.float32)
+    y = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5)
+    ref = y @ w.float().t() + b
+    if geglu:
+        h, gt = ref.chunk(2, dim=-1)
+        ref = h * F.gelu(gt)
+    wf, colsum, b2 = o.fold_layernorm(w, b, gamma, beta)
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        got = o.gemm(x.to(DEV), wf.to(DEV), bias=b2.to(DEV), flags=l.GEMM_GEGLU if geglu else 0,
+                     ln=(colsum.to(DEV), 1e-5))
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    check_close(results_log, f"gemm_ln_fused_{'_'.join(map(str, case))}_tile{tile}", got, ref, rel=3e-3, frac=2 ** -7)
+
+
 # ------------------------------------------------------------------ attention ----------------
 @pytest.mark.parametrize("case", [(1, 10, 1024, 1024, 1024), (2, 20, 256, 256, 256), (2, 5, 100, 80, 77),
                                   (1, 2, 64, 64, 64), (1, 10, 4096, 80, 77), (3, 4, 200, 200, 200)])
