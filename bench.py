@@ -9,25 +9,32 @@ programs replayed as hipGraphs; ``--frontier`` gaps evaluated per batched launch
 seeded synthetic SDXL-shaped tensors (no checkpoints offline), conditioning is synthetic.
 
 N > 1 (``torchrun``): one process per GPU, ``torch.distributed`` backend nccl (= RCCL over xGMI).  ONE
-transition tree is farmed over the ranks (latentblending_amd/dist/farm.py): anchors on ranks 0/1 and
-all-gathered, every speculative round's branches split over the ranks, latent stacks + decoded
-frames + LPIPS scalars all-gathered, identical greedy commits everywhere.  Per-GPU work is held
-fixed (weak scaling): nmb_max_branches = 15 x N  ->  15N + 2 frames per transition; `value` is the
-whole job's frames/s.
+transition tree is farmed over the ranks (latentblending_amd/dist/farm.py): every rank runs both anchors plus
+its share of the mid branches in one wavefront, ONE packed all-gather of (latent stack, frame) per round and one
+of the sharded LPIPS scalars, identical greedy commits everywhere.
+  --scaling strong (default): the metric's own workload — 15 mid branches (17 frames) whatever N is;
+  --scaling weak: per-GPU work fixed, nmb_max_branches = 15 x N -> 15N + 2 frames per transition;
+  --branches-total K: K mid branches in total (BASELINE configs[3]: 64 branches on 8 GPUs).
+`value` is the whole job's frames/s.  --metric-skew S replaces the perceptual metric by a deliberately skewed
+one (distance x exp(S x position)): the greedy order then leaves the balanced tree and the speculative frontier needs
+several small rounds — reported through census_per_transition.frontier_rounds / speculation_hit_rate.
 
 The JSON line also carries
-  roofline      — the dominant kernel family (MFMA GEMM / implicit-GEMM conv): algorithmic FLOPs
-                  per transition / its device time, measured live with hipEvents between the ops
-                  of an eager replay of the same launch programs, against the 2.5 PFLOP/s dense
-                  fp16 MFMA peak (guide: MI355X_MICROARCH.md);
+  roofline      — the dominant kernel family (MFMA GEMM / implicit-GEMM conv / halo-tile conv): algorithmic
+                  FLOPs per transition / its device time, measured live with hipEvents between the ops of an
+                  eager replay of the same launch programs, against the 2.5 PFLOP/s dense fp16 MFMA peak;
+  rooflines     — the same for every other kernel class on the path: attention (MFMA), GroupNorm / LayerNorm (HBM),
+                  the latent-mixing slerp (HBM: the engine's native-size launches and a >= 1 GiB batch timed here),
+                  scheduler input scaling + Euler step (HBM);
   cpu_baseline  — the CPU fp32 oracle (oracle/, a restatement = "port") timed on this box's host
-                  cores on a bounded sample (1 UNet forward + 1 VAE decode at the same shapes,
-                  scaled by the transition's census 38 / 17).
+                  cores on a bounded sample (UNet forwards + a VAE decode + LPIPS + slerps at the same shapes,
+                  scaled by the transition's census 38 / 17 / 30 / 60).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -48,53 +55,67 @@ def parse():
     ap.add_argument("--steps", type=int, default=3, help="timed transitions")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frontier", type=int, default=16, help="gap children evaluated per batched round (per GPU)")
-    ap.add_argument("--branches", type=int, default=15)
+    ap.add_argument("--branches", type=int, default=15, help="mid branches of the metric's workload")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--branches-total", type=int, default=0, help="total mid branches (overrides --scaling)")
+    ap.add_argument("--metric-skew", type=float, default=0.0, help="skew the perceptual metric by exp(S x position)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def census(pipe) -> dict:
-    return dict(pipe.stats)
-
-
 def gemm_family_profile(pipe, launches):
     """Eager hipEvent-timed replay of every launch program the transition used.
     launches: {("unet", B, L): count, ("vae", B, L): count}.  Returns totals per transition."""
-    tot = {"gemm_flops": 0.0, "gemm_ms": 0.0, "gemm_launches": 0, "attn_flops": 0.0, "attn_ms": 0.0,
-           "other_ms": 0.0, "all_ms": 0.0, "gemm_bytes": 0.0}
-    for (kind, B, L), count in launches.items():
+    tot = {"gemm_flops": 0.0, "gemm_ms": 0.0, "gemm_launches": 0, "attn_flops": 0.0, "attn_ms": 0.0, "attn_launches": 0,
+           "other_ms": 0.0, "all_ms": 0.0, "gemm_bytes": 0.0, "halo_ms": 0.0, "halo_flops": 0.0, "halo_launches": 0,
+           "gn_ms": 0.0, "gn_bytes": 0.0, "gn_launches": 0, "ln_ms": 0.0, "ln_bytes": 0.0, "ln_launches": 0,
+           "attn_self_ms": 0.0, "attn_self_flops": 0.0, "attn_cross_ms": 0.0, "attn_cross_flops": 0.0}
+    for (kind, B, L), cnt in launches.items():
         if kind == "unet":
             up = pipe.unet_program(B, L)
-            progs = [(up.prog_step, count)]
-            em = up.em
+            prog, em = up.prog_step, up.em
             n_cond_gemms = sum(1 for n in up.prog_cond.op_names() if n in GEMM_OPS)
-            logs = {id(up.prog_step): (em.gemm_log[n_cond_gemms:], em.attn_log)}
+            glog, alog, nlog = em.gemm_log[n_cond_gemms:], em.attn_log, em.norm_log
         else:
             vp = pipe.vae_program(B, L)
-            progs = [(vp.prog, count)]
-            logs = {id(vp.prog): (vp.em.gemm_log, vp.em.attn_log)}
-        for prog, cnt in progs:
-            prog.time_ops()                       # warm
-            ms = prog.time_ops()
-            names = prog.op_names()
-            glog, alog = logs[id(prog)]
-            gi = ai = 0
-            for n, t in zip(names, ms):
-                tot["all_ms"] += t * cnt
-                if n in GEMM_OPS:
-                    tot["gemm_flops"] += glog[gi]["flops"] * cnt
-                    tot["gemm_bytes"] += glog[gi]["bytes"] * cnt
-                    tot["gemm_ms"] += t * cnt
-                    tot["gemm_launches"] += cnt
-                    gi += 1
-                elif n == "lb_attn_fwd_d64":
-                    tot["attn_flops"] += alog[ai]["flops"] * cnt
-                    tot["attn_ms"] += t * cnt
-                    ai += 1
-                else:
-                    tot["other_ms"] += t * cnt
+            prog, glog, alog, nlog = vp.prog, vp.em.gemm_log, vp.em.attn_log, vp.em.norm_log
+        prog.time_ops()                       # warm
+        ms = prog.time_ops()
+        names = prog.op_names()
+        gi = ai = ni = 0
+        for n, t in zip(names, ms):
+            tot["all_ms"] += t * cnt
+            if n in GEMM_OPS:
+                tot["gemm_flops"] += glog[gi]["flops"] * cnt
+                tot["gemm_bytes"] += glog[gi]["bytes"] * cnt
+                tot["gemm_ms"] += t * cnt
+                tot["gemm_launches"] += cnt
+                if n == "lb_conv3x3_halo_f16":
+                    tot["halo_ms"] += t * cnt
+                    tot["halo_flops"] += glog[gi]["flops"] * cnt
+                    tot["halo_launches"] += cnt
+                gi += 1
+            elif n == "lb_attn_fwd_d64":
+                a = alog[ai]
+                tot["attn_flops"] += a["flops"] * cnt
+                tot["attn_ms"] += t * cnt
+                tot["attn_launches"] += cnt
+                key = "attn_self" if a.get("Skv", 0) == a.get("Sq", -1) else "attn_cross"
+                tot[key + "_ms"] += t * cnt
+                tot[key + "_flops"] += a["flops"] * cnt
+                ai += 1
+            elif n in ("lb_groupnorm_nhwc", "lb_layernorm_f16"):
+                k = "gn" if n == "lb_groupnorm_nhwc" else "ln"
+                while ni < len(nlog) and nlog[ni]["op"] != n:      # (the log is in emission order, both kinds mixed)
+                    ni += 1
+                tot[k + "_ms"] += t * cnt
+                tot[k + "_launches"] += cnt
+                tot[k + "_bytes"] += (nlog[ni]["bytes"] if ni < len(nlog) else 0.0) * cnt
+                ni += 1
+            else:
+                tot["other_ms"] += t * cnt
     return tot
 
 
@@ -117,40 +138,129 @@ def install_launch_counters(pipe, counts):
         prog.prog.launch = counted_v
 
 
-def roofline_block(prof, launch_counts):
-    achieved = prof["gemm_flops"] / (prof["gemm_ms"] * 1e-3) / 1e12 if prof["gemm_ms"] else 0.0
-    return {
-        "bound": "mfma", "kernel": "gemm_f16_glds_kernel<BM,BN,CONV,GEGLU,S,WMW> (all Linear/Conv of UNet+VAE)",
+def _tf(flops, ms):
+    return flops / (ms * 1e-3) / 1e12 if ms else 0.0
+
+
+def _gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9 if ms else 0.0
+
+
+def _event_time_us(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def mixing_rooflines(device, G=15, L=64):
+    """Latent-mixing primitives, timed live on the current stream: the engine's native-size launches (latency-bound)
+    and a >= 1 GiB batch of the same kernels against the 8 TB/s HBM roof (6 B / element: read p0, p1, write out;
+    Euler-ancestral step 8 B / element: read x, eps, noise, write x)."""
+    from latentblending_amd.hip import ops
+    from latentblending_amd.hip.lib import api
+    n = 4 * L * L
+    out = []
+    a, b = torch.randn(1, n, device=device).half(), torch.randn(1, n, device=device).half()
+    fr = torch.rand(G, device=device, dtype=torch.float64)
+    us_native = _event_time_us(lambda: ops.slerp_strided(a, b, fr, n, broadcast0=True, broadcast1=True), iters=50)
+    pairs = (1 << 30) // (n * 2 * 3)
+    p0, p1 = torch.randn(pairs, n, device=device).half(), torch.randn(pairs, n, device=device).half()
+    frb = torch.rand(pairs, device=device, dtype=torch.float64)
+    ob = torch.empty_like(p0)
+    us_big = _event_time_us(lambda: ops.slerp_strided(p0, p1, frb, n, out=ob), iters=5, warm=2)
+    gbs = pairs * n * 6 / us_big / 1e3
+    out.append({"kernel": "slerp_strided_kernel (interpolate_spherical: parental mix / crossfeed)", "bound": "hbm",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_element": 6, "batch": {"pairs": pairs, "elements_per_pair": n, "us": us_big},
+                "native_launch": {"pairs": G, "elements_per_pair": n, "us": us_native,
+                                  "note": "one launch per denoising step of the wavefront: launch-latency bound"}})
+    # scheduler: x_in = x / sqrt(sigma^2 + 1) and the Euler-ancestral update on the same >= 1 GiB batch
+    params = torch.zeros(pairs, 8, dtype=torch.float32, device=device)
+    params[:, 0], params[:, 1], params[:, 2], params[:, 4] = 1.6129, 0.6374, 0.6259, -0.9755
+    st = torch.cuda.current_stream().cuda_stream
+    us_scale = _event_time_us(lambda: api.lb_scale_model_input_f16(p0.data_ptr(), ob.data_ptr(), params.data_ptr(), n, pairs, 0, st),
+                              iters=5, warm=2)
+    us_step = _event_time_us(lambda: api.lb_euler_step_f16(p0.data_ptr(), p1.data_ptr(), ob.data_ptr(), ob.data_ptr(),
+                                                           params.data_ptr(), n, pairs, 0, 1, st), iters=5, warm=2)
+    g1, g2 = pairs * n * 4 / us_scale / 1e3, pairs * n * 8 / us_step / 1e3
+    out.append({"kernel": "scale_input_kernel (scheduler.scale_model_input)", "bound": "hbm", "achieved": g1,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBS, "algorithmic_bytes_per_element": 4})
+    out.append({"kernel": "euler_step_kernel (Euler-ancestral scheduler.step)", "bound": "hbm", "achieved": g2,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g2 / HBM_PEAK_GBS, "algorithmic_bytes_per_element": 8})
+    del p0, p1, ob
+    torch.cuda.empty_cache()
+    return out
+
+
+def roofline_blocks(prof, launch_counts, device):
+    achieved = _tf(prof["gemm_flops"], prof["gemm_ms"])
+    dominant = {
+        "bound": "mfma", "kernel": "gemm_f16_glds_kernel<BM,BN,CONV,GEGLU,S,WMW,LNA> + conv3x3_halo_kernel<BN,TW> "
+                                   "(every Linear / Conv of UNet + VAE)",
         "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
         "traffic": _pmc_traffic_per_launch(),
-        "traffic_unit": "HBM-side bytes per GEMM launch (rocprofv3 PMC passes committed in profiles/; null if absent)",
+        "traffic_unit": "HBM-side bytes per GEMM/conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                        "command committed in profiles/; null if absent)",
         "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
         "algorithmic_tflop_per_transition_reference": 103.1,
         "per_transition": {"gemm_tflop": prof["gemm_flops"] / 1e12, "gemm_ms": prof["gemm_ms"],
                            "gemm_launches": prof["gemm_launches"],
                            "gemm_avg_us_per_launch": prof["gemm_ms"] * 1e3 / max(prof["gemm_launches"], 1),
-                           "gemm_algorithmic_GBs": prof["gemm_bytes"] / (prof["gemm_ms"] * 1e-3) / 1e9 if prof["gemm_ms"] else 0,
-                           "attn_tflop": prof["attn_flops"] / 1e12, "attn_ms": prof["attn_ms"],
-                           "attn_TFLOPs": prof["attn_flops"] / (prof["attn_ms"] * 1e-3) / 1e12 if prof["attn_ms"] else 0,
+                           "gemm_algorithmic_GBs": _gbs(prof["gemm_bytes"], prof["gemm_ms"]),
+                           "halo_conv_tflop": prof["halo_flops"] / 1e12, "halo_conv_ms": prof["halo_ms"],
+                           "halo_conv_TFLOPs": _tf(prof["halo_flops"], prof["halo_ms"]),
+                           "attn_ms": prof["attn_ms"], "groupnorm_ms": prof["gn_ms"], "layernorm_ms": prof["ln_ms"],
                            "other_kernels_ms": prof["other_ms"], "all_program_ms_eager": prof["all_ms"],
                            "program_launches": {"%s_B%d_L%d" % k: v for k, v in launch_counts.items()}},
     }
+    a = _tf(prof["attn_flops"], prof["attn_ms"])
+    gn = _gbs(prof["gn_bytes"], prof["gn_ms"])
+    rest = [
+        {"kernel": "attn_fwd_d64_kernel<KT,QG,NS> (UNet self + cross attention, in situ)", "bound": "mfma", "achieved": a,
+         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F16_PEAK_TFLOPS,
+         "per_transition": {"tflop": prof["attn_flops"] / 1e12, "ms": prof["attn_ms"], "launches": prof["attn_launches"],
+                            "self_TFLOPs": _tf(prof["attn_self_flops"], prof["attn_self_ms"]), "self_ms": prof["attn_self_ms"],
+                            "cross_TFLOPs": _tf(prof["attn_cross_flops"], prof["attn_cross_ms"]), "cross_ms": prof["attn_cross_ms"]}},
+        {"kernel": "gn_partial_kernel + gn_apply_kernel (GroupNorm + SiLU, 3 passes)", "bound": "hbm",
+         "achieved": gn, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gn / HBM_PEAK_GBS,
+         "per_transition": {"ms": prof["gn_ms"], "launches": prof["gn_launches"], "GB": prof["gn_bytes"] / 1e9}},
+    ]
+    if prof["ln_launches"]:
+        ln = _gbs(prof["ln_bytes"], prof["ln_ms"])
+        rest.append({"kernel": "layernorm_kernel", "bound": "hbm", "achieved": ln, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ln / HBM_PEAK_GBS, "per_transition": {"ms": prof["ln_ms"], "launches": prof["ln_launches"]}})
+    else:
+        rest.append({"kernel": "layernorm", "note": "no LayerNorm launch exists: folded into the consuming GEMMs (LB_GEMM_LN_A)"})
+    try:
+        rest += mixing_rooflines(device)
+    except Exception as exc:                              # never lose the throughput line over a side measurement
+        rest.append({"kernel": "slerp / scheduler", "error": repr(exc)})
+    return dominant, rest
 
 
 def _pmc_traffic_per_launch():
     """HBM traffic of the GEMM family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE),
     per launch like `achieved`; PMC collection cannot run inside the timed bench itself."""
-    path = os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)["gemm_family_hbm_traffic"]["bytes_per_launch"]
-    except Exception:
-        return None
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")
+        try:
+            with open(path) as fh:
+                return json.load(fh)["gemm_family_hbm_traffic"]["bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
-def cpu_baseline(unet_w, vae_w):
-    """Bounded CPU sample on this host: one fp32 UNet forward + one fp32 VAE decode of the oracle
-    at the benchmark shapes (B=1, 64x64 latent), scaled by the transition census (38 / 17)."""
+def cpu_baseline(unet_w, vae_w, census):
+    """Bounded CPU sample on this host (~15-25 s): two fp32 UNet forwards, one fp32 VAE decode, one LPIPS pair and 16
+    slerps of the oracle at the benchmark shapes (B=1, 64x64 latent), scaled by the transition census."""
     from oracle import sdxl_ref as R
     cores = min(os.cpu_count() or 1, 16)     # more threads than this only slows torch's CPU GEMMs down
     torch.set_num_threads(cores)
@@ -161,16 +271,41 @@ def cpu_baseline(unet_w, vae_w):
     te = torch.randn(1, 1280, generator=g).half()
     ids = torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]])
     t0 = time.perf_counter()
-    R.unet_forward(ucfg, unet_w, x, torch.tensor(999.0), ctx, te, ids)
-    t_unet = time.perf_counter() - t0
+    for tt in (999.0, 749.0):
+        R.unet_forward(ucfg, unet_w, x, torch.tensor(tt), ctx, te, ids)
+    t_unet = (time.perf_counter() - t0) / 2
     t0 = time.perf_counter()
-    R.postprocess_u8(R.vae_decode(vcfg, vae_w, x.float() / vcfg.scaling_factor))
+    img = R.vae_decode(vcfg, vae_w, x.float() / vcfg.scaling_factor)
+    R.postprocess_u8(img)
     t_vae = time.perf_counter() - t0
-    t_transition = 38 * t_unet + 17 * t_vae
-    return {"value": 17.0 / t_transition, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 (torch CPU, {cores} threads): 1 UNet forward B=1 64x64 latent = {t_unet:.2f} s, "
-                      f"1 VAE decode = {t_vae:.2f} s; transition = 38 UNet + 17 VAE (census) = {t_transition:.1f} s "
-                      f"extrapolated; LPIPS/slerp/host excluded"}
+    lp = R.OracleLPIPS(7)
+    t0 = time.perf_counter()
+    lp(img.clamp(-1, 1), img.flip(-1).clamp(-1, 1))
+    t_lpips = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for k in range(16):
+        R.slerp(x, x.flip(-1), k / 16.0)
+    t_slerp = (time.perf_counter() - t0) / 16
+    n_unet, n_vae = census.get("unet_samples") or 38.0, census.get("vae_decodes") or 17.0
+    n_lp, n_sl = census.get("lpips_pairs") or 30.0, census.get("slerps") or 60.0
+    t_transition = n_unet * t_unet + n_vae * t_vae + n_lp * t_lpips + n_sl * t_slerp
+    return {"value": n_vae / t_transition, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 (torch CPU, {cores} threads): 2 UNet forwards B=1 64x64 latent = {t_unet:.2f} s each, "
+                      f"1 VAE decode = {t_vae:.2f} s, 1 LPIPS pair = {t_lpips:.2f} s, 16 slerps = {t_slerp * 1e3:.2f} ms each; "
+                      f"transition = {n_unet:.0f} UNet + {n_vae:.0f} VAE + {n_lp:.0f} LPIPS + {n_sl:.0f} slerp (census) "
+                      f"= {t_transition:.1f} s extrapolated"}
+
+
+def skewed_metric(be, skew):
+    """Policy stress test: the pipe's native LPIPS times exp(skew x mean position of the two frames).  The tree stays
+    exact (same greedy rule, same metric on both the sequential and the speculative path), only far less balanced."""
+    pipe = be.dh.pipe
+
+    def similarity(a, b, fa, fb):
+        d = pipe.native_frame_distances([(a, b)])[0]
+        fa, fb = (0.5 if fa is None else fa), (0.5 if fb is None else fb)
+        return d * math.exp(skew * 0.5 * (fa + fb))
+    return similarity
 
 
 def main():
@@ -211,11 +346,19 @@ def _run():
     if world > 1:
         from latentblending_amd.dist import BranchFarm
         farm = BranchFarm(device=torch.device("cuda", local_rank))
-    be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier * world, verbose=False,
-                        farm=farm)
+    if args.branches_total > 0:
+        branches, scaling = args.branches_total, "strong"
+    elif args.scaling == "weak":
+        branches, scaling = args.branches * world, "weak"
+    else:
+        branches, scaling = args.branches, "strong"
+    be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier * (world if scaling == "weak" else 1),
+                        verbose=False, farm=farm)
+    if args.metric_skew:
+        be.pair_metric = skewed_metric(be, args.metric_skew)
     be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
     be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
-    be.set_branching(nmb_max_branches=args.branches * world)
+    be.set_branching(nmb_max_branches=branches)
 
     def barrier():
         torch.cuda.synchronize()
@@ -228,6 +371,7 @@ def _run():
         frames = len(be.run_transition(fixed_seeds=[420, 421]))
     for k in pipe.stats:
         pipe.stats[k] = 0
+    be.stats.clear()
     farm_counts = {}
     if world > 1 and rank == 0 and not args.no_roofline and args.warmup > 0:
         # a farmed transition cannot be repeated by rank 0 alone (collectives), so rank 0 counts its own program
@@ -243,21 +387,24 @@ def _run():
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    per_transition = {k: v / max(args.steps, 1) for k, v in census(pipe).items()}
-    n_runs = max(args.steps + args.warmup, 1)
+    n_runs = max(args.steps, 1)
+    per_transition = {k: v / n_runs for k, v in pipe.stats.items()}
     per_transition["frontier_rounds"] = be.stats.get("frontier_rounds", 0) / n_runs
     per_transition["speculation_dropped"] = be.stats.get("speculation_dropped", 0) / n_runs
+    evaluated = be.stats.get("speculation_evaluated", 0) / n_runs
+    per_transition["speculation_evaluated"] = evaluated
+    per_transition["speculation_hit_rate"] = (evaluated - per_transition["speculation_dropped"]) / evaluated if evaluated else None
 
     out = {
         "metric": "transition frames/sec, SDXL-Turbo 512x512 4-step 15-branch",
         "value": frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "scaling": scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": "SDXL-Turbo 512x512, num_inference_steps=4, nmb_max_branches=%d (%d frames/transition), "
-                               "fp16, fixed_seeds=[420,421], anchors not recycled" % (args.branches * world, frames),
-                   "frontier_width": args.frontier, "hipgraphs": not args.no_graphs,
-                   "parallelism": ("branch farm over %d ranks (RCCL all-gather of anchors / branches)" % world)
-                   if world > 1 else "single GPU",
+                               "fp16, fixed_seeds=[420,421], anchors not recycled" % (branches, frames),
+                   "frontier_width": args.frontier, "hipgraphs": not args.no_graphs, "metric_skew": args.metric_skew,
+                   "parallelism": ("branch farm over %d ranks (RCCL: one packed all-gather of branches + one of LPIPS "
+                                   "scalars per round; anchors computed by every rank)" % world) if world > 1 else "single GPU",
                    "farm": None if farm is None else {"collectives": farm.collectives, "bytes_moved": farm.bytes_moved},
                    "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1)},
     }
@@ -267,16 +414,17 @@ def _run():
         install_launch_counters(pipe, step_launch_counts)
         be.run_transition(fixed_seeds=[420, 421])
         torch.cuda.synchronize()
-        out["roofline"] = roofline_block(gemm_family_profile(pipe, step_launch_counts), step_launch_counts)
+        out["roofline"], out["rooflines"] = roofline_blocks(gemm_family_profile(pipe, step_launch_counts), step_launch_counts,
+                                                            f"cuda:{local_rank}")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(unet_w, vae_w)
+        out["cpu_baseline"] = cpu_baseline(unet_w, vae_w, per_transition)
     if world > 1:
         dist.destroy_process_group()
         if rank == 0 and farm_counts:
             # rank 0's share of the farmed transition (its UNet / VAE batches), same eager hipEvent replay as N=1
             try:
                 per_tr = {k: v / max(args.steps, 1) for k, v in farm_counts.items()}
-                out["roofline"] = roofline_block(gemm_family_profile(pipe, per_tr), per_tr)
+                out["roofline"], out["rooflines"] = roofline_blocks(gemm_family_profile(pipe, per_tr), per_tr, f"cuda:{local_rank}")
                 out["roofline"]["scope"] = "rank 0's programs of the farmed transition"
             except Exception as exc:                      # never lose the throughput line over the profile
                 out["roofline"] = None

@@ -73,6 +73,8 @@ class BlendingEngine:
         self.mid_compression_scaler = mid_compression_scaler
         self.frontier_width = int(frontier_width)
         self.farm = farm
+        self.pair_metric = None             # optional callable(frame_a, frame_b, fract_a, fract_b) -> distance replacing the
+        #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
         self.seed1 = 0
@@ -428,8 +430,12 @@ class BlendingEngine:
         """Decode the branch, measure it against both neighbours and commit it."""
         frame = self.dh.latent2image(list_latents[-1])
         lo, hi = self.get_closest_idx(fract_mixing)
-        left = self.get_lpips_similarity(frame, self.tree_final_imgs[lo])
-        right = self.get_lpips_similarity(frame, self.tree_final_imgs[hi])
+        if self.pair_metric is not None:
+            left = float(self.pair_metric(frame, self.tree_final_imgs[lo], fract_mixing, self.tree_fracts[lo]))
+            right = float(self.pair_metric(frame, self.tree_final_imgs[hi], fract_mixing, self.tree_fracts[hi]))
+        else:
+            left = self.get_lpips_similarity(frame, self.tree_final_imgs[lo])
+            right = self.get_lpips_similarity(frame, self.tree_final_imgs[hi])
         self._tree.commit(fract_mixing, idx_injection, list_latents, frame, left, right)
 
     def _decode_many(self, latents: list):
@@ -485,11 +491,13 @@ class BlendingEngine:
                 mid_frames[k] = frames[2 + mine.index(k)]
         frame_at = {0.0: frames[0], 1.0: frames[1]}
         frame_at.update({m: f for (_, _, m), f in zip(gaps, mid_frames)})
-        sims = self._gap_child_distances([(frame_at[m], frame_at[fl], frame_at[fr]) for (fl, fr, m) in gaps])
+        sims = self._gap_child_distances([(frame_at[m], frame_at[fl], frame_at[fr]) for (fl, fr, m) in gaps],
+                                         [(m, fl, fr) for (fl, fr, m) in gaps])
         ready = {(fl, fr): dict(fract=m, traj=traj, frame=frame_at[m], sl=sims[k][0], sr=sims[k][1])
                  for k, ((fl, fr, m), traj) in enumerate(zip(gaps, mids))}
         self.guidance_scale = self.dh.guidance_scale = guid[-1]
         self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
+        self.stats["speculation_evaluated"] = self.stats.get("speculation_evaluated", 0) + len(gaps)
         return first, last, ready
 
     def _grow_level_frontier(self, idx_injection: int, stems: int, ready=None):
@@ -568,38 +576,41 @@ class BlendingEngine:
             frame_at.update({r["fract"]: r["frame"] for r in ready.values()})
             frame_at.update({s["fract"]: fr_ for s, (_, fr_) in zip(specs, results)})
             sims = self._gap_child_distances([(frame, frame_at[s["left"]], frame_at[s["right"]])
-                                              for s, (_, frame) in zip(specs, results)])
+                                              for s, (_, frame) in zip(specs, results)],
+                                             [(s["fract"], s["left"], s["right"]) for s in specs])
             for k, (s, (traj, frame)) in enumerate(zip(specs, results)):
                 ready[(s["left"], s["right"])] = dict(fract=s["fract"], traj=traj, frame=frame,
                                                       sl=sims[k][0], sr=sims[k][1])
             self.guidance_scale = self.dh.guidance_scale = specs[-1]["guidance"]
             self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
+            self.stats["speculation_evaluated"] = self.stats.get("speculation_evaluated", 0) + len(specs)
         self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
 
-    def _gap_child_distances(self, triples):
-        """[(child frame, left neighbour, right neighbour)] -> [(d_left, d_right)].  Under a farm the perceptual
-        metric is SHARDED: every rank measures only the children it owns (features of the frames involved are
-        computed on demand and cached) and the scalars are all-gathered, so all ranks decide on bit-identical
-        numbers."""
-        if not self._farm_on():
-            flat = []
-            for child, left, right in triples:
-                flat += [(child, left), (child, right)]
-            sims = self._frame_distances(flat)
-            return [(sims[2 * k], sims[2 * k + 1]) for k in range(len(triples))]
-        own = self.farm.my_indices(len(triples))
-        flat = []
+    def _gap_child_distances(self, triples, fracts):
+        """[(child frame, left neighbour, right neighbour)], [(f_child, f_left, f_right)] -> [(d_left, d_right)].
+        Under a farm the perceptual metric is SHARDED: every rank measures only the children it owns (features of
+        the frames involved are computed on demand and cached) and the scalars are all-gathered, so all ranks
+        decide on bit-identical numbers."""
+        own = self.farm.my_indices(len(triples)) if self._farm_on() else list(range(len(triples)))
+        flat, flat_f = [], []
         for k in own:
             child, left, right = triples[k]
+            fc, fl, fr = fracts[k]
             flat += [(child, left), (child, right)]
-        sims = self._frame_distances(flat)
+            flat_f += [(fc, fl), (fc, fr)]
+        sims = self._frame_distances(flat, flat_f)
+        if not self._farm_on():
+            return [(sims[2 * k], sims[2 * k + 1]) for k in range(len(triples))]
         got = self.farm.exchange_scalars([(sims[2 * j], sims[2 * j + 1]) for j in range(len(own))], len(triples))
         return [(g[0], g[1]) for g in got]
 
     def _latent_chw(self):
         return (int(self.dh.pipe.unet.config.in_channels), int(self.dh.height_latent), int(self.dh.width_latent))
 
-    def _frame_distances(self, pairs):
+    def _frame_distances(self, pairs, fracts=None):
+        if self.pair_metric is not None:
+            fracts = fracts or [(None, None)] * len(pairs)
+            return [float(self.pair_metric(a, b, fa, fb)) for (a, b), (fa, fb) in zip(pairs, fracts)]
         pipe = self.dh.pipe
         if _is_native(pipe) and self.lpips is getattr(pipe, "lpips_metric", None):
             return pipe.native_frame_distances(pairs) if pairs else []
@@ -769,6 +780,8 @@ class BlendingEngine:
     # ------------------------------------------------------------------ metric ------------
     def get_lpips_similarity(self, imgA, imgB):
         """Perceptual distance of two frames (high = dissimilar)."""
+        if self.pair_metric is not None:
+            return float(self.pair_metric(imgA, imgB, None, None))
         pipe = self.dh.pipe
         if _is_native(pipe) and self.lpips is getattr(pipe, "lpips_metric", None):
             return pipe.native_frame_distances([(imgA, imgB)])[0]

@@ -135,6 +135,7 @@ class Emitter:
         # algorithmic work of every emitted contraction, in emission order (bench.py roofline)
         self.gemm_log: List[dict] = []
         self.attn_log: List[dict] = []
+        self.norm_log: List[dict] = []      # GroupNorm / LayerNorm launches: algorithmic HBM bytes
         self._retired: List[torch.Tensor] = []
         self.zero_page = torch.zeros(64, dtype=torch.uint8, device=self.device)
 
@@ -203,11 +204,14 @@ class Emitter:
         api.lb_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                               self._gn_ws(B, groups).data_ptr(), B, HW, C_, ldx or C_, C_, groups, eps,
                               int(silu), int(x.dtype == F32), _stream())
+        # algorithmic traffic: the statistics pass reads x, the apply pass reads x and writes fp16 y
+        self.norm_log.append({"op": "lb_groupnorm_nhwc", "bytes": float(B * HW * C_) * (2 * x.element_size() + 2)})
         return out
 
     def layernorm(self, x, out, gamma, beta, *, M: int, C_: int, eps: float = 1e-5):
         api.lb_layernorm_f16(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, C_, C_, C_,
                              eps, _stream())
+        self.norm_log.append({"op": "lb_layernorm_f16", "bytes": float(M * C_) * 4})
         return out
 
     def attention(self, q_ptr: int, k_ptr: int, v_ptr: int, out: torch.Tensor, *, B, H, Sq, Skv, valid,
@@ -219,7 +223,7 @@ class Emitter:
         p.scale = 0.125
         p.zero_page = self.zero_page.data_ptr()
         api.lb_attn_fwd_d64(C.byref(p), _stream())
-        self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * 64})
+        self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * 64, "Sq": Sq, "Skv": Skv})
         return out
 
     def copy_cols(self, src, dst, *, rows, cols, ld_src, ld_dst, dst_off):

@@ -61,10 +61,12 @@ def _pad(n: int, m: int) -> int:
 
 
 class NativeUNet:
-    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm: bool = True):
-        """``fuse_layernorm``: the three LayerNorms of every transformer block are folded into the GEMMs that consume
-        them (no LayerNorm launch, no normalised copy of the hidden state); False keeps separate LayerNorm launches
-        (A/B studies, and the only form the register-ring GEMM variant supports)."""
+    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm: bool = False):
+        """``fuse_layernorm``: fold the three LayerNorms of every transformer block into the GEMMs that consume them
+        (LB_GEMM_LN_A: no LayerNorm launch, no normalised copy of the hidden state).  OFF by default: on MI355X the
+        row statistics accumulated inside the K loop (64 v_dot2 per K-tile and wave) cost the MFMA loop more than the
+        6 us LayerNorm launch they replace (profiles/r02_ln_gemm_bench.txt: QKV 57.1 + 6.4 us separate vs 70.0 us
+        fused at B=17; GEGLU 132 + 6 vs 166) - kept as a tested option for tile shapes / chips where the VALU is idle."""
         assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
         self.cfg, self.device = cfg, torch.device(device)
         self.fuse_layernorm = bool(fuse_layernorm)

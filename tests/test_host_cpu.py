@@ -569,3 +569,44 @@ def test_halo_conv_index_math(TW, H, W):
     # request accounting of one step: [halo?] + 2 weight loads; wait constant = loads of the two previous steps
     cnt = lambda tap: 2 + (1 if tap % 9 <= 4 else 0)
     assert [cnt(t - 1) + cnt(t - 2) for t in range(9)] == [4, 5, 6, 6, 6, 6, 5, 4, 4]
+
+
+# ---------------------------------------------------------------- speculation under a skewed metric
+@pytest.mark.parametrize("skew", [3.0, -4.0])
+def test_speculative_frontier_equals_sequential_under_skewed_metric(skew, cpu_backend):
+    """With a flat similarity landscape the level-order guess of the frontier is consumed completely; with a metric
+    that grows (or shrinks) exponentially along the transition the reference's greedy order leaves the balanced tree.
+    The speculative engine must still commit exactly the sequential tree (policy of
+    latentblending/blending_engine.py:531-588), merely in more rounds and with dropped speculation - both reported."""
+    import math
+    from latentblending_amd import BlendingEngine
+
+    def run(width):
+        p = tiny_pipe(turbo=True)
+        np.random.seed(0)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=width)
+        base = be.get_lpips_similarity
+
+        def skewed(a, b, fa, fb):
+            be.pair_metric = None
+            try:
+                d = base(a, b)
+            finally:
+                be.pair_metric = skewed
+            return d * math.exp(skew * 0.5 * (fa + fb))
+        be.pair_metric = skewed
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=9)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        p.noise.reset()
+        be.run_transition(fixed_seeds=[420, 421])
+        return be
+    seq, spec = run(1), run(4)
+    assert seq.tree_fracts == spec.tree_fracts and seq.tree_idx_injection == spec.tree_idx_injection
+    assert np.allclose([float(x) for x in seq.tree_similarities], [float(x) for x in spec.tree_similarities], rtol=1e-6)
+    balanced = [i / 10 for i in range(11)]
+    assert seq.tree_fracts != balanced                      # the skew really bends the tree
+    assert spec.stats["frontier_rounds"] >= 3               # ... which costs the frontier several rounds
+    assert spec.stats["speculation_evaluated"] >= 9
+    assert spec.stats["speculation_evaluated"] - spec.stats.get("speculation_dropped", 0) == 9

@@ -44,12 +44,13 @@ def make_pair(turbo=True, ucfg=None, vcfg=None, seed=0):
     return o, p, tape
 
 
-@pytest.mark.parametrize("B,L", [(1, 16), (2, 16), (3, 32)])
-def test_unet_tiny_matches_oracle(B, L, results_log):
+@pytest.mark.parametrize("B,L,fused_ln", [(1, 16, False), (2, 16, False), (3, 32, False), (2, 16, True), (3, 32, True)])
+def test_unet_tiny_matches_oracle(B, L, fused_ln, results_log):
+    """fused_ln: the LayerNorms folded into their consumer GEMMs (LB_GEMM_LN_A; an option, off by default)."""
     n = native()
     cfg = R.tiny_unet_cfg()
     w = R.make_weights(R.unet_spec(cfg), 0)
-    net = n.NativeUNet(n.UNetConfig(**dataclasses.asdict(cfg)), n.SyntheticProvider(0), DEV)
+    net = n.NativeUNet(n.UNetConfig(**dataclasses.asdict(cfg)), n.SyntheticProvider(0), DEV, fuse_layernorm=fused_ln)
     g = torch.Generator().manual_seed(B * 100 + L)
     x = torch.randn(B, 4, L, L, generator=g).half()
     ctx = torch.randn(B, 77, cfg.cross_dim, generator=g).half()
@@ -60,7 +61,7 @@ def test_unet_tiny_matches_oracle(B, L, results_log):
     prog.set_conditioning(ctx.to(DEV), te.to(DEV), ids.to(DEV))
     got = prog.forward(x.to(DEV), torch.full((B,), 499.0)).clone()
     r = rel_l2(got, ref)
-    results_log[f"unet_tiny_B{B}_L{L}_rel_l2"] = r
+    results_log[f"unet_tiny_B{B}_L{L}{'_fusedln' if fused_ln else ''}_rel_l2"] = r
     print(f"[parity] unet tiny B={B} L={L}: rel_l2={r:.3e} ops={prog.prog_step.num_ops}+{prog.prog_cond.num_ops}")
     assert torch.isfinite(got).all() and r <= 1e-2
     # graph replay == eager replay, bit for bit; a second timestep reuses the conditioning program
