@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--branches-total", type=int, default=0, help="total mid branches (overrides --scaling)")
     ap.add_argument("--metric-skew", type=float, default=0.0, help="skew the perceptual metric by exp(S x position)")
+    ap.add_argument("--config", choices=("cfg2", "cfg3"), default="cfg2",
+                    help="cfg2 = the metric's workload (SDXL-Turbo 512^2, 4 steps); cfg3 = BASELINE configs[2]: SDXL base "
+                         "1024^2, 30 steps, guidance 4.0, depth_strength 0.5, nmb_max_branches=15 (a secondary line)")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -335,10 +338,11 @@ def _run():
 
     # seeded synthetic SDXL weights from the product's own provider; rank 0 keeps the fp32 copies so
     # that the cpu_baseline leg can time the oracle on exactly the same parameters
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    base = args.config == "cfg3"
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not base
     t0 = time.perf_counter()
     unet_prov, vae_prov = N.SyntheticProvider(0, keep=want_cpu), N.SyntheticProvider(1, keep=want_cpu)
-    pipe = N.NativeSDXLPipe(turbo=True, unet_provider=unet_prov, vae_provider=vae_prov, device=f"cuda:{local_rank}",
+    pipe = N.NativeSDXLPipe(turbo=not base, unet_provider=unet_prov, vae_provider=vae_prov, device=f"cuda:{local_rank}",
                             allow_synthetic=True)      # ("data": "synthetic" in the JSON line)
     t_weights = time.perf_counter() - t0
     unet_w, vae_w = unet_prov.state, vae_prov.state
@@ -358,7 +362,10 @@ def _run():
         be.pair_metric = skewed_metric(be, args.metric_skew)
     be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
     be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
-    be.set_branching(nmb_max_branches=branches)
+    if base:
+        be.set_branching(depth_strength=0.5, nmb_max_branches=branches)
+    else:
+        be.set_branching(nmb_max_branches=branches)
 
     def barrier():
         torch.cuda.synchronize()
@@ -396,11 +403,15 @@ def _run():
     per_transition["speculation_hit_rate"] = (evaluated - per_transition["speculation_dropped"]) / evaluated if evaluated else None
 
     out = {
-        "metric": "transition frames/sec, SDXL-Turbo 512x512 4-step 15-branch",
+        "metric": "transition frames/sec, SDXL-Turbo 512x512 4-step 15-branch" if not base else
+                  "transition frames/sec, SDXL base 1024x1024 30-step guidance 4.0 nmb_max_branches=15 (BASELINE configs[2], secondary)",
         "value": frames * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": "SDXL-Turbo 512x512, num_inference_steps=4, nmb_max_branches=%d (%d frames/transition), "
+        "config": {"workload": ("SDXL base 1024x1024, num_inference_steps=30, guidance_scale=4.0 (mid-damped), depth_strength=0.5, "
+                                "nmb_max_branches=%d (%d frames/transition, levels %s x stems %s), fp16, fixed_seeds=[420,421]"
+                                % (branches, frames, list(be.list_idx_injection), list(be.list_nmb_stems))) if base else
+                               "SDXL-Turbo 512x512, num_inference_steps=4, nmb_max_branches=%d (%d frames/transition), "
                                "fp16, fixed_seeds=[420,421], anchors not recycled" % (branches, frames),
                    "frontier_width": args.frontier, "hipgraphs": not args.no_graphs, "metric_skew": args.metric_skew,
                    "parallelism": ("branch farm over %d ranks (RCCL: one packed all-gather of branches + one of LPIPS "
@@ -416,7 +427,7 @@ def _run():
         torch.cuda.synchronize()
         out["roofline"], out["rooflines"] = roofline_blocks(gemm_family_profile(pipe, step_launch_counts), step_launch_counts,
                                                             f"cuda:{local_rank}")
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not base:
         out["cpu_baseline"] = cpu_baseline(unet_w, vae_w, per_transition)
     if world > 1:
         dist.destroy_process_group()

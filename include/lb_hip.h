@@ -52,6 +52,8 @@ int lb_slerp_batched_f16(const void* p0, const void* p1, void* out, const double
 int lb_slerp_strided_f16(const void* p0, long stride0, const void* p1, long stride1, void* out,
                          const double* fracts_dev, long npairs, long n, void* stream);
 
+void lb_slerp_set_study(int variant);   /* tools/slerp_study.py only: 1 = lerp weights, 2 = fp32 sum (NOT the reference's arithmetic) */
+
 /* latentblending/utils.py:97 interpolate_linear on tensors (blending_engine.py:650) */
 int lb_lerp_f16(const void* p0, const void* p1, void* out, long n, double fract, void* stream);
 int lb_lerp_f32(const void* p0, const void* p1, void* out, long n, double fract, void* stream);
@@ -75,6 +77,8 @@ enum {
     LB_GEMM_TRANS_OUT = 8,   /* store C^T: C[n*ldc + m] */
     LB_GEMM_SILU = 16,       /* SiLU after bias/residual */
     LB_GEMM_RELU = 32,       /* ReLU after bias/residual */
+    LB_GEMM_QUICK_GELU = 128,/* x * sigmoid(1.702 x) after bias (CLIP-L MLP) */
+    LB_GEMM_GELU = 256,      /* erf GELU after bias (OpenCLIP bigG MLP) */
     LB_GEMM_LN_A = 64        /* A is consumed through a LayerNorm over its K columns (K = the normalised width):
                                 C = LN(A) . Wt computed as rstd_m * (A . W'^T - mean_m * colsum) + bias with
                                 W' = W * gamma (folded by the caller), ln_colsum[n] = sum_k W'[n][k],
@@ -149,7 +153,7 @@ typedef struct LbAttnParams {
     int B, H, Sq, Skv, Skv_valid;   /* keys >= Skv_valid are masked (context padding 77 -> 80) */
     int ldq, ldk, ldv, ldo;         /* Q, K, V may be column slices of one fused [tokens][3C] projection */
     float scale;         /* 1/sqrt(64) */
-    int reserved_;
+    int causal;          /* 1: key k is visible to query q only when k <= q (CLIP text towers); needs Sq == Skv */
     const void* zero_page;          /* >= 16 zero bytes, 16-B aligned: source of the direct-to-LDS loads of rows >= Skv */
 } LbAttnParams;
 int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
@@ -177,6 +181,10 @@ int lb_maxpool3s2_nhwc_f16(const void* x, void* y, int N, int H, int W, int C, v
 int lb_lpips_tap(const void* const* feats_a, const void* const* feats_b, const float* lin, float* acc,
                  float* workspace, int npairs, int HW, int C, void* stream);
 int lb_fill_f32(void* x, long n, float v, void* stream);
+/* CLIP text towers behind pipe.encode_prompt (diffusers_holder.py:79-96): CLIPTextEmbeddings and the EOS-row gather */
+int lb_embed_tokens_f16(const int* ids_dev, const void* tok_emb, const void* pos_emb, void* out, int rows, int seq, int C,
+                        int vocab, void* stream);
+int lb_gather_rows_f16(const void* src, const int* rows_idx_dev, void* out, int n, int C, int ld_src, void* stream);
 int lb_copy_d2d(void* dst, const void* src, long bytes, void* stream);
 
 /* ---- launch programs (the MI355X-native stand-in for the reference's optional stable-fast

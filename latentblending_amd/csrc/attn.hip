@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
             }
         }
         // ---- online softmax (this lane: one query per group, keys 16 kb + 4 g + r of the tile) ----
-        const bool ragged = (t + 1) * KT > p.Skv_valid;           // wave-uniform: only the last tile(s) mask
+        // wave-uniform: only the last tile(s) mask; a causal wave masks from the tile holding its first query on
+        const bool ragged = (t + 1) * KT > p.Skv_valid || (p.causal && (t + 1) * KT > q0);
         f16x8 pf[QG][NKS];
 #pragma unroll
         for (int qg = 0; qg < QG; ++qg) {
@@ -190,7 +191,10 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
                 for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (t * KT + kb * 16 + 4 * g + r >= p.Skv_valid) sacc[qg][kb][r] = -INFINITY;
+                    {
+                        const int key = t * KT + kb * 16 + 4 * g + r;
+                        if (key >= p.Skv_valid || (p.causal && key > q0 + qg * 16 + l16)) sacc[qg][kb][r] = -INFINITY;
+                    }
             }
             float mx = -INFINITY;
 #pragma unroll
@@ -309,6 +313,7 @@ extern "C" int lb_attn_fwd_d64(const LbAttnParams* pp, void* stream) {
     LB_REQUIRE(p.Skv_valid > 0 && p.Skv_valid <= p.Skv, "lb_attn_fwd_d64: 0 < Skv_valid <= Skv");
     LB_REQUIRE(p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && p.ldo % 4 == 0, "lb_attn_fwd_d64: ld alignment");
     LB_REQUIRE(p.zero_page != nullptr, "lb_attn_fwd_d64: zero_page (>= 16 zero bytes) is required");
+    LB_REQUIRE(!p.causal || p.Sq == p.Skv, "lb_attn_fwd_d64: causal attention needs Sq == Skv");
     const int force = g_attn_force;
     LB_DISPATCH("lb_attn_fwd_d64", attn_dispatch(p, force, s));
 }

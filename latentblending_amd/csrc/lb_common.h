@@ -97,6 +97,11 @@ __device__ __forceinline__ float lb_erf(float x) {
     return __builtin_copysignf(r, x);
 }
 
+// CLIP's "quick_gelu": x * sigmoid(1.702 x)
+__device__ __forceinline__ float lb_quick_gelu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.44269504088896340736f)));
+}
+
 __device__ __forceinline__ float lb_gelu_erf(float x) {
     return 0.5f * x * (1.0f + lb_erf(x * 0.70710678118654752440f));
 }

@@ -38,6 +38,10 @@ __device__ __forceinline__ void lb_gemm_store4(const LbGemmParams& p, int m, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
     }
+    if (p.flags & (LB_GEMM_QUICK_GELU | LB_GEMM_GELU)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (p.flags & LB_GEMM_GELU) ? lb_gelu_erf(o[r]) : lb_quick_gelu(o[r]);
+    }
     long crow = m;                      // output row; sub-pixel convs scatter to the 2x-upsampled grid
     if (p.scatter) {
         const int hw = p.Hout * p.Wout;
@@ -196,6 +200,10 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             if (p.flags & LB_GEMM_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+            }
+            if (p.flags & (LB_GEMM_QUICK_GELU | LB_GEMM_GELU)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (p.flags & LB_GEMM_GELU) ? lb_gelu_erf(o[r]) : lb_quick_gelu(o[r]);
             }
             lb_gemm_write4(p, crow, m, n, o);
         }

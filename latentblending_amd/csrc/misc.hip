@@ -253,3 +253,48 @@ __global__ void fill_f32_kernel(float* x, long n, float v) {
 extern "C" int lb_fill_f32(void* x, long n, float v, void* stream) {
     LB_DISPATCH_STMT("lb_fill_f32", hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, (float*)x, n, v));
 }
+
+// ------------------------------------------------------------------------------------------
+// CLIP text towers (encode_prompt, /root/reference/latentblending/diffusers_holder.py:79-96):
+// out[r][:] = token_embedding[ids[r]][:] + position_embedding[r % seq][:]   (CLIPTextEmbeddings)
+// ------------------------------------------------------------------------------------------
+__global__ void embed_tokens_kernel(const int* __restrict__ ids, const f16* __restrict__ tok,
+                                    const f16* __restrict__ pos, f16* __restrict__ out, int rows, int seq, int C, int vocab) {
+    const int vecs = C >> 3;
+    const long total = (long)rows * vecs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / vecs), v = (int)(i - (long)r * vecs);
+        int id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f16x8 a = *reinterpret_cast<const f16x8*>(tok + (long)id * C + v * 8);
+        const f16x8 b = *reinterpret_cast<const f16x8*>(pos + (long)(r % seq) * C + v * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)a[e] + (float)b[e]);
+        *reinterpret_cast<f16x8*>(out + (long)r * C + v * 8) = o;
+    }
+}
+
+extern "C" int lb_embed_tokens_f16(const int* ids_dev, const void* tok_emb, const void* pos_emb, void* out, int rows,
+                                   int seq, int C, int vocab, void* stream) {
+    LB_REQUIRE(rows > 0 && seq > 0 && C > 0 && C % 8 == 0 && vocab > 0, "lb_embed_tokens_f16: sizes (C multiple of 8)");
+    LB_DISPATCH_STMT("lb_embed_tokens_f16", hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for((long)rows * (C / 8))), dim3(256), 0, s,
+                       ids_dev, (const f16*)tok_emb, (const f16*)pos_emb, (f16*)out, rows, seq, C, vocab));
+}
+
+// out[i][:] = src[rows_idx[i]][:]  (the EOS-token row of every prompt: pooled CLIP output)
+__global__ void gather_rows_kernel(const f16* __restrict__ src, const int* __restrict__ idx, f16* __restrict__ out, int n, int C,
+                                   int ld_src) {
+    const int vecs = C >> 3;
+    const long total = (long)n * vecs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / vecs), v = (int)(i - (long)r * vecs);
+        *reinterpret_cast<f16x8*>(out + (long)r * C + v * 8) = *reinterpret_cast<const f16x8*>(src + (long)idx[r] * ld_src + v * 8);
+    }
+}
+
+extern "C" int lb_gather_rows_f16(const void* src, const int* rows_idx_dev, void* out, int n, int C, int ld_src, void* stream) {
+    LB_REQUIRE(n > 0 && C > 0 && C % 8 == 0 && ld_src % 8 == 0, "lb_gather_rows_f16: sizes (C, ld multiples of 8)");
+    LB_DISPATCH_STMT("lb_gather_rows_f16", hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (C / 8))), dim3(256), 0, s,
+                       (const f16*)src, rows_idx_dev, (f16*)out, n, C, ld_src));
+}

@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict_
 // VPT 16-byte vectors of both inputs in REGISTERS between the reduction and the weighted sum: HBM is read exactly
 // once (6 B / element) without an LDS round trip, the block needs 0.5 KiB of LDS, so four 512-thread blocks share a
 // CU and one block's loads overlap another's float64 arithmetic.
-template <int VPT>
+// STUDY: 0 = product; 1 = lerp weights instead of the acos / sin chain; 2 = fp32 weighted sum (tools/slerp_study.py only)
+template <int VPT, int STUDY = 0>
 __global__ void __launch_bounds__(512) slerp_strided_kernel(const f16* __restrict__ p0, long stride0,
                                                              const f16* __restrict__ p1, long stride1,
                                                              f16* __restrict__ out, const double* __restrict__ fracts,
@@ -181,15 +182,18 @@ __global__ void __launch_bounds__(512) slerp_strided_kernel(const f16* __restric
         }
     block_sum3(dot, s0, s1, red);
     double w0, w1;
-    slerp_weights_block(dot, s0, s1, fracts[b], w0, w1, red);
+    if (STUDY == 1) { w1 = fracts[b] + 1e-30 * dot; w0 = 1.0 - w1; }
+    else slerp_weights_block(dot, s0, s1, fracts[b], w0, w1, red);
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const long i = threadIdx.x + (long)j * 512;
         if (i < nvec) {
             f16x8 r;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
+            for (int e = 0; e < 8; ++e) {
+                if (STUDY == 2) { r[e] = (f16)((float)va[j][e] * (float)w0 + (float)vb[j][e] * (float)w1); continue; }
                 r[e] = lb_f64_to_f16(__dadd_rn(__dmul_rn((double)va[j][e], w0), __dmul_rn((double)vb[j][e], w1)));
+            }
             *reinterpret_cast<f16x8*>(o + i * 8) = r;
         }
     }
@@ -272,10 +276,22 @@ static int slerp_batched_impl(const void* p0, const void* p1, void* out, const d
     return lb_check_launch("lb_slerp_batched_f16");
 }
 
+static int g_slerp_study = 0;
+extern "C" void lb_slerp_set_study(int v) { g_slerp_study = v; }
+
 static int slerp_strided_impl(const void* p0, long stride0, const void* p1, long stride1, void* out,
                               const double* fracts_dev, long npairs, long n, hipStream_t stream) {
     const long nvec = n >> 3;
     const dim3 grid((unsigned)npairs), block(512);
+    if (g_slerp_study && nvec > 1024 && nvec <= 2048) {      // bottleneck studies on the L = 64 latent size only
+        if (g_slerp_study == 1)
+            hipLaunchKernelGGL((slerp_strided_kernel<4, 1>), grid, block, 0, stream, (const f16*)p0, stride0, (const f16*)p1, stride1,
+                               (f16*)out, fracts_dev, n);
+        else
+            hipLaunchKernelGGL((slerp_strided_kernel<4, 2>), grid, block, 0, stream, (const f16*)p0, stride0, (const f16*)p1, stride1,
+                               (f16*)out, fracts_dev, n);
+        return lb_check_launch("lb_slerp_strided_f16(study)");
+    }
 #define LB_SLERP_STRIDED(V) hipLaunchKernelGGL((slerp_strided_kernel<V>), grid, block, 0, stream, (const f16*)p0, stride0, \
                                                (const f16*)p1, stride1, (f16*)out, fracts_dev, n)
     if (nvec <= 512) LB_SLERP_STRIDED(1);

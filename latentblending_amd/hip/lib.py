@@ -41,11 +41,12 @@ class LbAttnParams(C.Structure):
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("Sq", C.c_int), ("Skv", C.c_int), ("Skv_valid", C.c_int),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
-        ("scale", C.c_float), ("reserved_", C.c_int), ("zero_page", C.c_void_p),
+        ("scale", C.c_float), ("causal", C.c_int), ("zero_page", C.c_void_p),
     ]
 
 
 GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU, GEMM_LN_A = 1, 2, 4, 8, 16, 32, 64
+GEMM_QUICK_GELU, GEMM_GELU = 128, 256
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "lb_slerp_pairs_f64": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
     "lb_slerp_batched_f16": (_i, [_vp, _vp, _vp, _vp, _l, _l, _vp]),
     "lb_slerp_strided_f16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _l, _vp]),
+    "lb_slerp_set_study": (None, [_i]),
     "lb_lerp_f16": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_lerp_f32": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_scale_model_input_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
@@ -89,6 +91,8 @@ SIGNATURES = {
     "lb_maxpool3s2_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lb_lpips_tap": (_i, [c_void_pp, c_void_pp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "lb_fill_f32": (_i, [_vp, _l, _f, _vp]),
+    "lb_embed_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "lb_gather_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "lb_copy_d2d": (_i, [_vp, _vp, _l, _vp]),
     "lb_program_create": (_vp, []),
     "lb_program_destroy": (None, [_vp]),
@@ -104,7 +108,7 @@ SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

@@ -256,7 +256,7 @@ def zero_page(device) -> torch.Tensor:
 
 def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
                   skv_valid: Optional[int] = None, ldq=None, ldk=None, ldv=None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, causal: bool = False) -> torch.Tensor:
     """q: [B*Sq, >=H*64], k, v: [B*Skv, >=H*64] (row strides may exceed widths: slices of a fused QKV buffer)."""
     p = LbAttnParams()
     if out is None:
@@ -265,6 +265,7 @@ def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: 
     p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, skv_valid or Skv
     p.ldq, p.ldk, p.ldv, p.ldo = ldq or q.stride(0), ldk or k.stride(0), ldv or v.stride(0), out.stride(0)
     p.scale = 0.125
+    p.causal = int(causal)
     p.zero_page = zero_page(q.device).data_ptr()
     api.lb_attn_fwd_d64(C.byref(p), stream_ptr())
     return out

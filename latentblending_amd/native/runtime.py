@@ -215,12 +215,13 @@ class Emitter:
         return out
 
     def attention(self, q_ptr: int, k_ptr: int, v_ptr: int, out: torch.Tensor, *, B, H, Sq, Skv, valid,
-                  ldq, ldk, ldv, ldo):
+                  ldq, ldk, ldv, ldo, causal: bool = False):
         p = LbAttnParams()
         p.Q, p.K, p.V, p.O = q_ptr, k_ptr, v_ptr, out.data_ptr()
         p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, valid
         p.ldq, p.ldk, p.ldv, p.ldo = ldq, ldk, ldv, ldo
         p.scale = 0.125
+        p.causal = int(causal)
         p.zero_page = self.zero_page.data_ptr()
         api.lb_attn_fwd_d64(C.byref(p), _stream())
         self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * 64, "Sq": Sq, "Skv": Skv})

@@ -106,6 +106,45 @@ def test_full_vae_B17_matches_oracle(full_models, results_log):
     torch.cuda.empty_cache()
 
 
+# ------------------------------------------------------------------ BASELINE configs[2] shapes: SDXL base, 1024^2
+def test_full_unet_and_vae_at_1024_match_oracle(full_models, results_log):
+    """SDXL base 1.0 at 1024x1024 (latent 128x128): the CFG batch of one denoising step (B = 2: [uncond | text]) through
+    the full UNet - self-attention over 4096 tokens, 16x the attention work of the 512^2 programs - and one VAE decode
+    (mid-block attention over 16384 tokens), against the fp32 oracle."""
+    m = full_models
+    g = torch.Generator().manual_seed(3128)
+    B, L = 2, 128
+    x = torch.randn(B, 4, L, L, generator=g).half()
+    ctx = torch.randn(B, 77, 2048, generator=g).half()
+    ctx[0] = 0                                                       # the reference's zeroed negative conditioning
+    te = torch.randn(B, 1280, generator=g).half()
+    te[0] = 0
+    ids = torch.tensor([[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]] * B)
+    prog = m["unet"].build(B, L)
+    prog.set_conditioning(ctx.to(DEV), te.to(DEV), ids.to(DEV))
+    got = prog.forward(x.to(DEV), torch.full((B,), 958.0)).clone()
+    worst = 0.0
+    for b in range(B):
+        ref = R.unet_forward(m["ucfg"], m["uw"], x[b:b + 1], torch.tensor(958.0), ctx[b:b + 1], te[b:b + 1], ids[b:b + 1])
+        worst = max(worst, rel_l2(got[b:b + 1], ref))
+    results_log["unet_full_B2_L128_worst_rel_l2"] = worst
+    print(f"[parity] FULL SDXL UNet B=2 1024^2: worst per-sample rel_l2={worst:.3e}")
+    assert torch.isfinite(got).all() and worst <= 1e-2
+    del prog
+    torch.cuda.empty_cache()
+    z = torch.randn(1, 4, L, L, generator=g).half()
+    vprog = m["vae"].build(1, L)
+    got_u8 = vprog.decode(z.to(DEV)).cpu().numpy()
+    ref_img = R.vae_decode(m["vcfg"], m["vw"], z.float() / m["vcfg"].scaling_factor)
+    rv = rel_l2(vprog.image_f32[..., :3].permute(0, 3, 1, 2), ref_img)
+    d = np.abs(got_u8.astype(np.int32) - R.postprocess_u8(ref_img).astype(np.int32))
+    results_log["vae_full_L128"] = {"rel_l2": rv, "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean())}
+    print(f"[parity] FULL SDXL VAE 1024^2: rel_l2={rv:.3e} mean|du8|={d.mean():.3f} within4={(d <= 4).mean():.4f}")
+    assert rv <= 1e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99
+    del vprog
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ one whole benchmark transition
 def test_cfg2_transition_matches_oracle(full_models, results_log):
     """BASELINE configs[1] end to end: SDXL-Turbo 512^2, 4 steps, 15 mid branches -> 17 frames.  Native engine

@@ -440,6 +440,36 @@ def test_attention_d64_variants(case, force, results_log):
     check_close(results_log, f"attn_f{force}_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
 
 
+@pytest.mark.parametrize("force", [0, 1, 2, 17])
+@pytest.mark.parametrize("case", [(2, 12, 77), (1, 3, 200), (2, 2, 64)])
+def test_attention_causal(case, force, results_log):
+    """Causal mask of the CLIP text towers (key k visible to query q iff k <= q), single-tile and streamed forms."""
+    o, l = ops(), lib()
+    B, H, S = case
+    C = H * 64
+    q, k, v = rnd(B, S, C, seed=64), rnd(B, S, C, seed=65), rnd(B, S, C, seed=66)
+    qh, kh, vh = [t.float().view(B, S, H, 64).transpose(1, 2) for t in (q, k, v)]
+    ref = F.scaled_dot_product_attention(qh, kh, vh, is_causal=True).transpose(1, 2).reshape(B, S, C)
+    l.api.lb_attn_set_tuning(force)
+    try:
+        got = o.attention_d64(q.reshape(B * S, C).to(DEV), k.reshape(B * S, C).to(DEV), v.reshape(B * S, C).to(DEV), B, H, S, S,
+                              causal=True)
+    finally:
+        l.api.lb_attn_set_tuning(0)
+    check_close(results_log, f"attn_causal_f{force}_{'_'.join(map(str, case))}", got.reshape(B, S, C), ref, floor=2e-3)
+
+
+def test_gemm_gelu_epilogues(results_log):
+    """Non-gated activations of the CLIP MLPs in the GEMM epilogue: quick-GELU (x sigmoid(1.702 x)) and erf-GELU."""
+    o, l = ops(), lib()
+    x, w, b = rnd(154, 768, seed=87), rnd(3072, 768, seed=88, scale=768 ** -0.5), rnd(3072, seed=89, dtype=torch.float32)
+    y = x.float() @ w.float().t() + b
+    got_q = o.gemm(x.to(DEV), w.to(DEV), bias=b.to(DEV), flags=l.GEMM_QUICK_GELU)
+    check_close(results_log, "gemm_quick_gelu", got_q, y * torch.sigmoid(1.702 * y))
+    got_g = o.gemm(x.to(DEV), w.to(DEV), bias=b.to(DEV), flags=l.GEMM_GELU)
+    check_close(results_log, "gemm_gelu_erf", got_g, F.gelu(y))
+
+
 def test_attention_spiked_scores(results_log):
     """Force large running-max jumps between KV tiles (online-softmax rescale path)."""
     o = ops()

@@ -318,11 +318,15 @@ def test_branch_farm_on_rccl_world1(results_log):
         farm_world = farm.world
         be_b, ib = run(farm)
         assert be_a.tree_fracts == be_b.tree_fracts
-        t = farm.share_trajectory(be_a.tree_latents[0], 0, 4)
+        t = farm.share_trajectory(be_a.tree_latents[0], 0, 4)                       # broadcast on RCCL
         assert all(torch.equal(a, b.reshape(a.shape)) for a, b in zip(t, be_a.tree_latents[0]))
-        res = farm.exchange_branches([(be_a.tree_latents[1], ia[1], 0.25, 0.5)], 1, 2, 4, make_frame=be_a._frame_from_u8)
-        assert res[0][2:] == (0.25, 0.5) and torch.equal(res[0][0][-1], be_a.tree_latents[1][-1])
+        res = farm.exchange_branches([(be_a.tree_latents[1], ia[1])], 1, 2, 4, be_a._frame_from_u8, be_a._latent_chw(),
+                                     (be_a.dh.height_img, be_a.dh.width_img))      # packed all-gather on RCCL
+        assert torch.equal(res[0][0][-1].cpu(), be_a.tree_latents[1][-1].cpu()) and res[0][0][0] is None
         assert np.array_equal(np.asarray(res[0][1]), np.asarray(ia[1]))
+        assert farm.exchange_scalars([(0.25, 0.5)], 1) == [[0.25, 0.5]]
+        farm.check_consistent([1.0, 2.0, 3.0])
+        assert farm.broadcast_floats([4.5, 6.0]) == [4.5, 6.0]
         results_log["farm_rccl_world1"] = {"collectives": farm.collectives, "bytes": farm.bytes_moved}
     finally:
         dist.destroy_process_group()
@@ -383,3 +387,91 @@ def test_branch_farm_with_native_pipes_two_ranks(tmp_path, results_log):
     assert r0["samples"] < solo["samples"] and r1["samples"] < solo["samples"]
     results_log["farm_native_2ranks"] = {"samples": [r0["samples"], r1["samples"], solo["samples"]],
                                          "collectives": r0["collectives"]}
+
+
+# ------------------------------------------------------------------ text conditioning
+def _hf_clip(cfg_native, seed):
+    """transformers' own CLIP text tower (random init, CPU fp32): a third-party oracle that IS importable here."""
+    from transformers import CLIPTextConfig as HFConfig, CLIPTextModel, CLIPTextModelWithProjection
+    c = cfg_native
+    hf = HFConfig(vocab_size=c.vocab_size, hidden_size=c.hidden_size, intermediate_size=c.intermediate_size,
+                  num_hidden_layers=c.num_hidden_layers, num_attention_heads=c.num_attention_heads,
+                  max_position_embeddings=c.max_position_embeddings, hidden_act=c.hidden_act,
+                  layer_norm_eps=c.layer_norm_eps, projection_dim=c.projection_dim or 512,
+                  bos_token_id=c.bos_token_id, eos_token_id=c.eos_token_id, pad_token_id=c.pad_token_id)
+    torch.manual_seed(seed)
+    model = (CLIPTextModelWithProjection if c.projection_dim else CLIPTextModel)(hf).eval()
+    with torch.no_grad():                     # HF's default init (std 0.02) leaves the towers nearly linear: widen it
+        for name, prm in model.named_parameters():
+            if prm.dim() == 2 and "embedding" not in name:
+                prm.mul_(2.5)
+        for prm in model.parameters():        # both sides must see fp16-representable parameters
+            prm.copy_(prm.half().float())
+    return model
+
+
+@pytest.mark.parametrize("which", ["tiny", "clip_l", "openclip_bigg"])
+def test_clip_text_tower_matches_transformers(which, results_log):
+    """Native CLIP text towers (encode_prompt's device work, diffusers_holder.py:79-96) against
+    transformers.CLIPTextModel / CLIPTextModelWithProjection evaluated on the CPU in fp32 with the same parameters:
+    penultimate hidden states (what SDXL conditions on) and the projected EOS embedding (pooled)."""
+    n = native()
+    if which == "tiny":
+        cfg = n.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                               num_attention_heads=2, hidden_act="gelu", projection_dim=64, bos_token_id=998,
+                               eos_token_id=999, pad_token_id=1)
+    else:
+        cfg = getattr(n.CLIPTextConfig, which)()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    hf = _hf_clip(cfg, 5)
+    tower = n.NativeCLIPText(cfg, n.DictProvider({k: v.detach() for k, v in hf.state_dict().items()}), DEV)
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    ids = torch.randint(2, cfg.bos_token_id - 1, (B, 77), generator=g)
+    ids[:, 0] = cfg.bos_token_id
+    for b, n_tok in enumerate((9, 40)):
+        ids[b, n_tok] = cfg.eos_token_id
+        ids[b, n_tok + 1:] = cfg.pad_token_id
+    with torch.no_grad():
+        out = hf(input_ids=ids, output_hidden_states=True)
+    ref_h = out.hidden_states[-2]
+    got_h, got_p = tower.forward(ids)
+    rh = rel_l2(got_h, ref_h)
+    res = {"penultimate_rel_l2": rh}
+    assert torch.isfinite(got_h).all() and rh <= 5e-3, rh
+    if cfg.projection_dim:
+        rp = rel_l2(got_p, out.text_embeds)
+        res["pooled_rel_l2"] = rp
+        assert rp <= 1e-2, rp
+    results_log[f"clip_text_{which}"] = res
+    print(f"[parity] CLIP text tower {which}: {res}")
+
+
+def test_prompt_conditioning_through_the_pipe(results_log):
+    """encode_prompt with native text towers: shapes / dtypes of the 4-tuple the holder consumes, prompt sensitivity,
+    CFG negatives, and a transition driven by them."""
+    n = native()
+    from latentblending_amd import BlendingEngine
+    c1 = n.CLIPTextConfig(vocab_size=2000, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                          bos_token_id=1998, eos_token_id=1999, pad_token_id=1999)
+    c2 = n.CLIPTextConfig(vocab_size=2000, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                          hidden_act="gelu", projection_dim=128, bos_token_id=1998, eos_token_id=1999, pad_token_id=0)
+    enc = n.NativeTextEncoders(n.NativeCLIPText(c1, n.SyntheticProvider(3), DEV), n.NativeCLIPText(c2, n.SyntheticProvider(4), DEV),
+                               allow_synthetic=True)
+    ucfg, vcfg = R.tiny_unet_cfg(), R.tiny_vae_cfg()            # cross_dim 256 = 128 + 128, pooled_dim 128
+    pipe = n.NativeSDXLPipe(turbo=True, unet_cfg=n.UNetConfig(**dataclasses.asdict(ucfg)),
+                            vae_cfg=n.VAEConfig(**dataclasses.asdict(vcfg)), text_encoder_fn=enc.encode)
+    pe, npe, pooled, npooled = pipe.encode_prompt("photo of a reef", do_classifier_free_guidance=True, negative_prompt="blurry")
+    assert pe.shape == (1, 77, 256) and pooled.shape == (1, 128) and pe.dtype == torch.float16
+    assert npe.shape == pe.shape and not torch.equal(npe, pe)
+    pe2 = pipe.encode_prompt("rendering of an alien planet", do_classifier_free_guidance=False)[0]
+    assert not torch.equal(pe, pe2)
+    assert torch.equal(pe, pipe.encode_prompt("photo of a reef", do_classifier_free_guidance=False)[0])   # deterministic
+    be = BlendingEngine(pipe, verbose=False, frontier_width=4)
+    be.set_dimensions((128, 128))
+    be.set_branching(nmb_max_branches=3)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+    imgs = be.run_transition(fixed_seeds=[5, 6])
+    assert len(imgs) == 5
+    results_log["prompt_conditioning_pipe"] = {"frames": len(imgs)}
