@@ -312,7 +312,7 @@ static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     }
 }
 
-static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64, direct-to-LDS only: 4=256x128 5=256x256
+static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64, direct-to-LDS only: 4=256x128 5=256x256 7=192x128
 static int g_force_splitk = 0;    // 0 auto
 static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
@@ -425,9 +425,20 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
             const long b512 = blocks(256, 256);
             const long rounds4 = (b256 + 255) / 256, rounds5 = (b512 + 255) / 256;
             if (allow5 && (b512 >= 1024 || (b512 >= 160 && p.K >= 1024)) && rounds5 * 174 < rounds4 * 100) tile = 5;
+            // 192x128 (6 waves): 3/4 of a 256x128 tile's work per block.  Taken when that shortens the schedule over
+            // the 256 CUs: M = 4352 x N = 1280 is ONE round of 230 blocks instead of one round of 170 full-size ones;
+            // M = 17408 x N = 640 two rounds of 3/4-size blocks instead of two rounds of full-size ones.
+            // Cost per block relative to 256x128: 0.78 measured-in-advance estimate (3/4 of the MFMA work + the same
+            // prologue / epilogue); only plain, non-GEGLU contractions, and only when the tile it replaces is 256x128 / 256x256.
+            if (!(g_policy_off & 32) && !geglu && !p.conv && (tile == 4 || tile == 5) && n_fits) {
+                const long b192 = blocks(192, 128);
+                const long rounds7 = (b192 + 255) / 256;
+                const long cur = tile == 5 ? rounds5 * 174 : rounds4 * 100;
+                if (b192 >= 160 && rounds7 * 78 < cur) tile = 7;
+            }
         }
     }
-    if (tile >= 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 8-wave tiles: direct-to-LDS family only
+    if (tile >= 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 6- / 8-wave tiles: direct-to-LDS family only
     // long-K problems with 1-2.5 small tiles per CU (B=2 convs of the UNet: M=2048, N=640, K=5760): no split
     // is possible at 64x64 (> 256 blocks), so they crawl through ~90 K-tiles per block.  Take 128x64 tiles
     // (half the blocks) and let the split-K rule below spread K instead.
@@ -435,7 +446,8 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         const long b64 = blocks(64, 64);
         if (b64 > 256 && b64 <= 640 && blocks(128, 64) <= 256) tile = 2;
     }
-    const int bm = tile >= 4 ? 256 : (tile == 3 ? 64 : 128), bn = tile == 5 ? 256 : ((tile == 1 || tile == 4) ? 128 : 64);
+    const int bm = tile == 7 ? 192 : (tile >= 4 ? 256 : (tile == 3 ? 64 : 128));
+    const int bn = tile == 5 ? 256 : ((tile == 1 || tile == 4 || tile == 7) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
     if (!geglu && p.partial != nullptr && !(p.flags & LB_GEMM_LN_A)) {     // (LN_A: a block must see whole rows of A)
@@ -502,7 +514,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     int stages = g_stages;
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
-        if (stages == 0) stages = (tile == 3 || tile == 4) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
+        if (stages == 0) stages = (tile == 3 || tile == 4 || tile == 7) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

@@ -51,17 +51,23 @@ __device__ __forceinline__ void ln_accumulate(const f16x8 (&af)[TM], float (&sum
         }
 }
 
-// WMW = waves along M (2 -> 4 waves / 256 threads, 4 -> 8 waves / 512 threads); always 2 waves along N
+// WMW = waves along M (2 -> 4 waves / 256 threads, 3 -> 6 waves / 384 threads, 4 -> 8 waves / 512 threads); always 2
+// waves along N.  The 6-wave 192x128 tile exists for wave quantisation: M = 4352 (17 samples x 256 tokens) makes
+// 170 tiles of 256x128 (2/3 of the chip, one round) but 230 tiles of 192x128 at 3/4 of the work each.  Its weight
+// tile (128 rows) is not a multiple of the 48 rows one round of its 384 threads stages: the third round is half
+// masked (rows >= BN fetch the zero page into 16 padding rows of the stage).
 template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, bool LNA = false>
 __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmParams p) {
     constexpr int NT = WMW * 128;           // threads per block
     constexpr int RPI = NT / 8;             // tile rows covered by one round of wave instructions
     constexpr int AI = BM * 8 / NT;         // wave instructions (16-B chunks per thread) of A per K-tile
-    constexpr int WI = BN * 8 / NT;
+    constexpr int WI = (BN * 8 + NT - 1) / NT;
     constexpr int NL = AI + WI;             // VMEM loads per thread per K-tile
     constexpr int WROWS = BM / WMW;         // rows of the block tile owned by one wave
+    constexpr int WPAD = WI * RPI;          // weight rows staged per K-tile (>= BN)
+    static_assert(BM * 8 % NT == 0, "A tile rows must be a whole number of staging rounds");
     constexpr int TM = WROWS / 16, TN = BN / 32;
-    constexpr int STAGE = (BM + BN) * BK;   // halves per ring stage
+    constexpr int STAGE = (BM + WPAD) * BK; // halves per ring stage
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
 
     const int tid = threadIdx.x;
@@ -132,12 +138,12 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
         if (GEGLU) {
             const int sub = tr >> 4;
             n = (sub & 1) * (p.N / 2) + n0 + (sub >> 1) * 16 + (tr & 15);
-            w_ok[i] = (n0 + (sub >> 1) * 16 + (tr & 15)) < p.N / 2;
+            w_ok[i] = tr < BN && (n0 + (sub >> 1) * 16 + (tr & 15)) < p.N / 2;
         } else {
             n = n0 + tr;
-            w_ok[i] = n < p.N;
+            w_ok[i] = tr < BN && n < p.N;
         }
-        w_off[i] = (long)n * p.ldw;
+        w_off[i] = w_ok[i] ? (long)n * p.ldw : 0;
     }
     const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
     const int hin_eff = p.Hin << p.ups, win_eff = p.Win << p.ups;
@@ -330,9 +336,15 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
                                          n0 + wave_n * (BN / 64) * 16 + 4 * g);
 }
 
+template <int BM, int BN, int WMW>
+constexpr int glds_stage_rows() {                       // A rows + weight rows incl. the padding of a partial staging round
+    constexpr int NT = WMW * 128, RPI = NT / 8, WI = (BN * 8 + NT - 1) / NT;
+    return BM + WI * RPI;
+}
+
 template <int BM, int BN, int S, int WMW = 2>
 static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
-    const size_t smem = (size_t)S * (BM + BN) * BK * sizeof(f16);
+    const size_t smem = (size_t)S * glds_stage_rows<BM, BN, WMW>() * BK * sizeof(f16);
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
     const dim3 block(WMW * 128);
     const bool lna = (p.flags & LB_GEMM_LN_A) != 0;
@@ -347,7 +359,7 @@ static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t str
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside of any stream capture
 template <int BM, int BN, int S, int WMW = 2>
 static void allow_lds() {
-    const int smem = S * (BM + BN) * BK * (int)sizeof(f16);
+    const int smem = S * glds_stage_rows<BM, BN, WMW>() * BK * (int)sizeof(f16);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>),
@@ -369,10 +381,13 @@ void lb_gemm_glds_init() {
     allow_lds<64, 64, 2>(); allow_lds<64, 64, 3>(); allow_lds<64, 64, 4>();
     allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4>();
     allow_lds<256, 256, 2, 4>();
+    allow_lds<192, 128, 3, 3>();
 }
 
-// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave); stages: 2..4 (0 = default for the tile)
+// tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave),
+// 7 = 192x128 (6 waves, 3-stage ring); stages: 2..4 (0 = default for the tile)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
+    if (tile == 7) return launch_glds_variant<192, 128, 3, 3>(p, grid, stream);            // 3 x 42 KiB
     if (tile == 5) return launch_glds_variant<256, 256, 2, 4>(p, grid, stream);     // 128 KiB: two stages only
     if (tile == 4) {
         if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);

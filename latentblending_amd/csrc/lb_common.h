@@ -70,11 +70,21 @@ __device__ __forceinline__ float lb_wave_max(float v) {
     return v;
 }
 
-// f64 -> f16 with a single rounding (round-to-odd f64->f32, then RN f32->f16).
+// f64 -> f16 with a single rounding: round-to-odd f64 -> f32, then RN f32 -> f16 (13 spare bits).  The round-to-odd
+// value is built from the ROUND-TO-NEAREST conversion (one v_cvt_f32_f64) and the exact residual x - f: if the
+// residual points towards zero, f overshot and the truncated value is one ulp below in magnitude; any non-zero
+// residual sets the sticky LSB.  (__double2float_rz has no single-instruction form here: hipcc emulated it with ~7
+// float64 operations per element, which made the batched slerp VALU-bound at 2.8 TB/s.)
 __device__ __forceinline__ f16 lb_f64_to_f16(double x) {
-    float f = __double2float_rz(x);
-    if ((double)f != x) f = __uint_as_float(__float_as_uint(f) | 1u);
-    return (f16)f;
+    const float f = (float)x;
+    const double r = x - (double)f;                                  // exact (Sterbenz / representable difference)
+    unsigned u = __float_as_uint(f);
+    const bool finite_nz = (u & 0x7fffffffu) - 1u < 0x7f7fffffu;      // f is neither 0, inf nor NaN
+    if (finite_nz && r != 0.0) {
+        if ((r < 0.0) != (f < 0.0f)) u -= 1u;                        // residual opposes f: truncate the magnitude
+        u |= 1u;
+    }
+    return (f16)__uint_as_float(u);
 }
 
 // SiLU / erf-GELU for epilogues and bandwidth-bound passes: raw v_exp_f32 / v_rcp_f32 (1 ulp), no IEEE division

@@ -63,11 +63,15 @@ class NativeCLIPText:
     """One CLIP text tower.  ``forward(ids)`` -> (penultimate hidden states [B, 77, C] fp16,
     projected EOS embedding [B, P] fp16 or None)."""
 
-    def __init__(self, cfg: CLIPTextConfig, provider, device="cuda", prefix: str = "text_model."):
+    def __init__(self, cfg: CLIPTextConfig, provider, device="cuda", prefix: Optional[str] = None):
         assert cfg.hidden_size % 64 == 0 and cfg.hidden_size // cfg.num_attention_heads == 64, "head_dim must be 64"
         assert cfg.hidden_act in ("quick_gelu", "gelu")
         self.cfg, self.device = cfg, torch.device(device)
         self.w: Dict[str, torch.Tensor] = {}
+        if prefix is None:      # HF checkpoints nest the tower under "text_model." or not, depending on class / version
+            state = getattr(provider, "state", None) or {}
+            base = getattr(provider, "prefix", "")
+            prefix = "" if (base + "embeddings.token_embedding.weight") in state else "text_model."
         c, pv, p = cfg.hidden_size, provider, prefix
 
         def dev(t, dt):
@@ -93,7 +97,7 @@ class NativeCLIPText:
         self.w["final.w"] = dev(pv.norm_weight(p + "final_layer_norm.weight", c), F32)
         self.w["final.b"] = dev(pv.bias(p + "final_layer_norm.bias", c), F32)
         if cfg.projection_dim:
-            root = prefix[:-len("text_model.")] if prefix.endswith("text_model.") else ""
+            root = prefix[:-len("text_model.")] if prefix.endswith("text_model.") else prefix
             self.w["proj"] = dev(pv.weight(root + "text_projection.weight", (cfg.projection_dim, c), c), F16)
         self._programs: Dict[int, "_CLIPProgram"] = {}
 

@@ -533,7 +533,7 @@ def test_small_kernels(results_log):
 
 # ------------------------------------------------------------------ direct-to-LDS GEMM variant
 @pytest.mark.parametrize("stages", [2, 3, 4])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7])
 def test_gemm_glds_variant(tile, stages, results_log):
     """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references."""
     o, l = ops(), lib()
