@@ -120,7 +120,7 @@ typedef struct LbGemmParams {
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
-void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5 and split-K */
+void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5 or 7 (192x128) and split-K */
 void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */
 int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /* the tile (1..5) / split-K / grid lb_gemm_f16 would use; launches nothing */
 /* 3x3 / stride 1 / pad 1 conv from an LDS-resident halo tile; same parameter block as lb_gemm_f16 (conv = 1,
@@ -129,7 +129,7 @@ int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /
  * (default), 2 = whenever eligible. */
 int lb_conv3x3_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
-void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv */
+void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv, bit5 ENABLES the 192x128 rule (off by default) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached

@@ -425,12 +425,12 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
             const long b512 = blocks(256, 256);
             const long rounds4 = (b256 + 255) / 256, rounds5 = (b512 + 255) / 256;
             if (allow5 && (b512 >= 1024 || (b512 >= 160 && p.K >= 1024)) && rounds5 * 174 < rounds4 * 100) tile = 5;
-            // 192x128 (6 waves): 3/4 of a 256x128 tile's work per block.  Taken when that shortens the schedule over
-            // the 256 CUs: M = 4352 x N = 1280 is ONE round of 230 blocks instead of one round of 170 full-size ones;
-            // M = 17408 x N = 640 two rounds of 3/4-size blocks instead of two rounds of full-size ones.
-            // Cost per block relative to 256x128: 0.78 measured-in-advance estimate (3/4 of the MFMA work + the same
-            // prologue / epilogue); only plain, non-GEGLU contractions, and only when the tile it replaces is 256x128 / 256x256.
-            if (!(g_policy_off & 32) && !geglu && !p.conv && (tile == 4 || tile == 5) && n_fits) {
+            // 192x128 (6 waves): 3/4 of a 256x128 tile's work per block, meant for wave quantisation (M = 4352 x N = 1280
+            // is 170 blocks of 256x128 = 2/3 of the chip, but 230 blocks of 192x128).  MEASURED (profiles/
+            // r02_tile7_bench.txt): a 192x128 block costs ~0.95 of a 256x128 block, not 0.78 - the K loop is bound per CU
+            // (1.1-1.3 us per K-tile whether the chip is full or 2/3 empty), so the smaller tile only wins 3-6 % on two
+            // shapes and loses on the rest.  OFF by default; lb_gemm_set_policy bit 5 turns the rule on for A/B studies.
+            if ((g_policy_off & 32) && !geglu && !p.conv && (tile == 4 || tile == 5) && n_fits) {
                 const long b192 = blocks(192, 128);
                 const long rounds7 = (b192 + 255) / 256;
                 const long cur = tile == 5 ? rounds5 * 174 : rounds4 * 100;
