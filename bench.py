@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-GEMM_OPS = ("lb_gemm_f16", "lb_conv3x3_halo_f16")      # one kernel family: MFMA GEMM / implicit-GEMM conv / halo-tile conv
+GEMM_OPS = ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16")      # one kernel family: MFMA GEMM / implicit-GEMM conv / halo-tile conv
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
 
@@ -95,7 +95,7 @@ def gemm_family_profile(pipe, launches):
                 tot["gemm_bytes"] += glog[gi]["bytes"] * cnt
                 tot["gemm_ms"] += t * cnt
                 tot["gemm_launches"] += cnt
-                if n == "lb_conv3x3_halo_f16":
+                if n != "lb_gemm_f16":
                     tot["halo_ms"] += t * cnt
                     tot["halo_flops"] += glog[gi]["flops"] * cnt
                     tot["halo_launches"] += cnt

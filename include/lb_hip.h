@@ -112,7 +112,8 @@ typedef struct LbGemmParams {
      * output parity (sc_py, sc_px), with pre-summed weights (4/9 of the FLOPs).  scatter = 1:
      * KH = KW = 2, Hout = Hin, Wout = Win, pad is implied (1 - parity) and row m = (b, y, x) is
      * stored at pixel (2y + sc_py, 2x + sc_px) of the [B][2H][2W][ldc] output. */
-    int scatter, sc_py, sc_px, reserved_;
+    int scatter, sc_py, sc_px, reserved_;   /* scatter = 2: ALL four parities in one launch, W = [4][N][ldw] stacked
+                                             * (parity py*2+px), halo-tile kernel only (lb_upconv2x_halo_f16) */
     const float* ln_colsum;  /* LB_GEMM_LN_A: [N] fp32 column sums of W' */
     float ln_eps;            /* LB_GEMM_LN_A: LayerNorm epsilon */
     int reserved2_;
@@ -128,6 +129,9 @@ int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /
  * (lb_gemm_plan reports tile code 6); lb_gemm_set_halo: 0 = never, 1 = when the halo grid fills the chip
  * (default), 2 = whenever eligible. */
 int lb_conv3x3_halo_f16(const LbGemmParams* params, void* stream);
+/* "nearest-2x upsample, then 3x3 conv" (UNet / VAE upsamplers) as ONE launch of the halo-tile kernel in its 2x2 sub-pixel
+ * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
+int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
 void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv, bit5 ENABLES the 192x128 rule (off by default) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */

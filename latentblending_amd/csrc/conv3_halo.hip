@@ -1,4 +1,5 @@
-// 3x3 / stride 1 / pad 1 convolution from an LDS-resident HALO tile (gfx950).  On the default route of
+// 3x3 / stride 1 / pad 1 convolution - and the sub-pixel 2x2 form of the upsampler convs - from an LDS-resident HALO
+// tile (gfx950).  On the default route of
 // lb_gemm_f16 since round 2 (lb_gemm_set_halo; measured 1.27-1.79x the implicit GEMM, up to 1.18 PFLOP/s).
 //
 // Why: the implicit-GEMM conv (gemm_glds.hip) stages every input pixel once per tap - 9 times - and the
@@ -36,17 +37,37 @@ template <int N> __device__ __forceinline__ void halo_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BN, int TW>
+// KS = 3: the 3x3 / stride 1 / pad 1 convolution described above (9 taps per 64-channel chunk).
+// KS = 2: the SUB-PIXEL form of "nearest-2x upsample, then 3x3 conv" (LbGemmParams.scatter == 2): four 2x2 convolutions
+//   on the low-res grid, one per output parity (py, px), with pre-summed weights stacked [4][N][4 Cin].  ALL FOUR
+//   parities run in this one launch (the parity is part of the block index: 4x the blocks of one parity launch, one
+//   launch instead of four); a block's halo is (TH+1) x (TW+1) pixels starting at (y0 - (1-py), x0 - (1-px)), its
+//   4 taps per chunk read it through shifted rows, and its 256 x BN results are scattered to pixels (2y+py, 2x+px).
+//   The next chunk's halo (5 rounds of wave instructions) is requested during taps 0 and 1 (3 + 2 rounds), because
+//   the wait before a step only guarantees everything older than the two previous steps.
+template <int KS, int J> struct HaloSched {             // tap during which round J of the NEXT chunk's halo is requested
+    static constexpr int tap = KS == 3 ? J : (J < 3 ? 0 : 1);
+};
+template <int KS, int NR, int TAP> constexpr int halo_full_rounds_in_tap() {   // rounds EVERY wave issues in step TAP
+    int n = 0;
+    for (int j = 0; j < NR - 1; ++j) n += ((KS == 3 ? j : (j < 3 ? 0 : 1)) == TAP) ? 1 : 0;   // (the last round is partial: counted as absent)
+    return n;
+}
+
+template <int BN, int TW, int KS = 3>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p) {
     constexpr int TH = 256 / TW;
-    constexpr int HWP = TW + 2;                         // halo width in pixels
-    constexpr int HR = (TH + 2) * HWP;                  // halo pixels (LDS rows in use)
+    constexpr int NTAP = KS * KS;
+    constexpr int HWP = TW + KS - 1;                    // halo width in pixels
+    constexpr int HR = (TH + KS - 1) * HWP;             // halo pixels (LDS rows in use)
     constexpr int HRG = (HR + 7) / 8;                   // 8-row groups = wave instructions per halo
     constexpr int HRP = HRG * 8;                        // rows per halo buffer
-    constexpr int EXTRA = HRG - 40;                     // groups left after 5 rounds of 8 waves (1..3)
+    constexpr int NR = (HRG + 7) / 8;                   // rounds of 8 wave instructions (the last one partial)
+    constexpr int EXTRA = HRG - 8 * (NR - 1);           // groups of the last, partial round (1..8)
     constexpr int WI = BN * 8 / 512;                    // weight loads per thread and step (2)
     constexpr int TM = 4, TN = BN / 32;                 // 16x16 tiles per wave (64 pixels x BN/2 channels)
-    static_assert(EXTRA >= 1 && EXTRA <= 8, "halo row groups must fit 6 rounds of 8 waves");
+    static_assert(NR == (KS == 3 ? 6 : 5), "halo rounds: 6 for the 3x3 form, 5 for the 2x2 form");
+    static_assert(EXTRA >= 1 && EXTRA <= 8, "the last halo round is a partial one");
     static_assert(WI == 2, "the vmcnt schedule assumes two weight loads per thread and step");
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
     f16* const halo0 = lds;
@@ -67,12 +88,20 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     }
     const int block_n = bid % n_blocks;
     int tile = bid / n_blocks;
+    int par_y = 0, par_x = 0;                           // output parity of a sub-pixel block
+    if (KS == 2) {
+        par_x = tile & 1;
+        par_y = (tile >> 1) & 1;
+        tile >>= 2;
+    }
     const int tx = tile % tiles_x;
     tile /= tiles_x;
     const int ty = tile % tiles_y;
     const int b = tile / tiles_y;
     const int n0 = block_n * BN;
     const int y0 = ty * TH, x0 = tx * TW;
+    const int org_y = KS == 3 ? 1 : 1 - par_y, org_x = KS == 3 ? 1 : 1 - par_x;     // halo row 0 / col 0 = pixel (y0 - org_y, x0 - org_x)
+    const lb_half* Wp = p.W + (KS == 2 ? (long)(par_y * 2 + par_x) * p.N * p.ldw : 0);
     const int nchunks = p.Cin / 64;
     const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
 
@@ -81,14 +110,14 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     // logical chunk slot ^ r8 of halo row gidx*8 + r8
     const int r8 = lane >> 3;
     const int cl = (lane & 7) ^ r8;
-    long h_off[6];                                      // element offset of the pixel (chunk 0), -1 = zero page
+    long h_off[NR];                                     // element offset of the pixel (chunk 0), -1 = zero page
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int gidx = j < 5 ? j * 8 + wave : 40 + wave;
+    for (int j = 0; j < NR; ++j) {
+        const int gidx = j * 8 + wave;
         const int row = gidx * 8 + r8;
         const int hy = row / HWP, hx = row - hy * HWP;
-        const int y = y0 + hy - 1, x = x0 + hx - 1;
-        const bool ok = (j < 5 || wave < EXTRA) && row < HR && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+        const int y = y0 + hy - org_y, x = x0 + hx - org_x;
+        const bool ok = (j < NR - 1 || wave < EXTRA) && row < HR && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
         h_off[j] = ok ? ((long)(b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 : -1;
     }
     // weights: thread stages rows (tid>>3) + 64 i of the BN x 64 tile
@@ -102,13 +131,13 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     auto issue_halo = [&](int j, int chunk) {           // one wave instruction of the halo of `chunk`
         const bool live = h_off[j] >= 0 && chunk < nchunks;
         const lb_half* src = live ? p.A + h_off[j] + (long)chunk * 64 : zero;
-        const int gidx = j < 5 ? j * 8 + wave : 40 + wave;
+        const int gidx = j * 8 + wave;
         f16* dst = halo0 + (chunk & 1) * (HRP * 64) + gidx * 8 * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
     auto issue_weight = [&](int i, int chunk, int tap, int slot) {
         const bool live = w_off[i] >= 0 && chunk < nchunks;
-        const lb_half* src = live ? p.W + w_off[i] + (long)tap * p.Cin + (long)chunk * 64 : zero;
+        const lb_half* src = live ? Wp + w_off[i] + (long)tap * p.Cin + (long)chunk * 64 : zero;
         f16* dst = wring + slot * (BN * 64) + (wave * 8 + i * 64) * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
@@ -121,7 +150,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         const int m = wave_m * 64 + i * 16 + l16;
         const int py = m / TW, px = m - py * TW;
         hbase[i] = py * HWP + px;
-        mrow[i] = (b * p.Hin + y0 + py) * p.Win + x0 + px;
+        mrow[i] = (b * p.Hin + y0 + py) * p.Win + x0 + px;     // (low-res pixel index; the epilogue scatters it for KS == 2)
     }
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -152,8 +181,8 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
 
     // ---- prologue: halo of chunk 0, weight tiles of steps 0..2 ----------------------------------------
 #pragma unroll
-    for (int j = 0; j < 6; ++j)
-        if (j < 5 || wave < EXTRA) issue_halo(j, 0);
+    for (int j = 0; j < NR; ++j)
+        if (j < NR - 1 || wave < EXTRA) issue_halo(j, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -162,25 +191,29 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     // one step; TAP is a compile-time constant so that every count below is an immediate
     auto step = [&](auto tap_c, int c) {
         constexpr int TAP = decltype(tap_c)::value;
-        constexpr int P1 = (TAP + 8) % 9, P2 = (TAP + 7) % 9;          // taps of the two previous steps
-        constexpr int CNT = (2 + (P1 <= 4 ? 1 : 0)) + (2 + (P2 <= 4 ? 1 : 0));
+        constexpr int P1 = (TAP + NTAP - 1) % NTAP, P2 = (TAP + NTAP - 2) % NTAP;          // taps of the two previous steps
+        constexpr int CNT = (2 + halo_full_rounds_in_tap<KS, NR, P1>()) + (2 + halo_full_rounds_in_tap<KS, NR, P2>());
         halo_wait_barrier<CNT>();
-        const int slot = (c + TAP) & 3;                  // (9 c + TAP) mod 4
+        const int slot = KS == 3 ? ((c + TAP) & 3) : TAP;   // (NTAP c + TAP) mod 4
         const f16* hb = halo0 + (c & 1) * (HRP * 64);
         const f16* wb = wring + slot * (BN * 64);
-        constexpr int KY = TAP / 3, KX = TAP % 3;
-        // the tap's row shift goes through an opaque register: the 72 swizzled fragment addresses of the nine
-        // taps are loop-invariant, and hoisting them out of the chunk loop costs more registers than the file has
+        constexpr int KY = TAP / KS, KX = TAP % KS;
+        // the tap's row shift goes through an opaque register: the swizzled fragment addresses of all taps are
+        // loop-invariant, and hoisting them out of the chunk loop costs more registers than the file has
         int shift = KY * HWP + KX;
         asm volatile("" : "+v"(shift));
-        // requests of this step: halo part of chunk c+1 (taps 0..5), then W(step + 3)
-        constexpr int TAP3 = (TAP + 3) % 9;
-        const int c3 = c + (TAP + 3) / 9;
+        // requests of this step: rounds of the halo of chunk c+1 scheduled here, then W(step + 3)
+        constexpr int TAP3 = (TAP + 3) % NTAP;
+        const int c3 = c + (TAP + 3) / NTAP;
         const int slot3 = (slot + 3) & 3;
         f16x8 a0[TM], w0[TN], a1[TM], w1[TN];
         read_frags(hb, wb, shift, 0, a0, w0);
-        if (TAP <= 4) issue_halo(TAP, c + 1);
-        else if (TAP == 5) { if (wave < EXTRA) issue_halo(5, c + 1); }
+        if constexpr (HaloSched<KS, 0>::tap == TAP) issue_halo(0, c + 1);
+        if constexpr (NR > 2 && HaloSched<KS, 1>::tap == TAP) issue_halo(1, c + 1);
+        if constexpr (NR > 3 && HaloSched<KS, 2>::tap == TAP) issue_halo(2, c + 1);
+        if constexpr (NR > 4 && HaloSched<KS, 3>::tap == TAP) { if (NR - 1 > 3 || wave < EXTRA) issue_halo(3, c + 1); }
+        if constexpr (NR > 4 && HaloSched<KS, 4>::tap == TAP) { if (NR - 1 > 4 || wave < EXTRA) issue_halo(4, c + 1); }
+        if constexpr (NR > 5 && HaloSched<KS, 5>::tap == TAP) { if (wave < EXTRA) issue_halo(5, c + 1); }
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a0, w0, 0, TM / 2);
         read_frags(hb, wb, shift, 1, a1, w1);
@@ -199,33 +232,70 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         step(std::integral_constant<int, 1>{}, c);
         step(std::integral_constant<int, 2>{}, c);
         step(std::integral_constant<int, 3>{}, c);
-        step(std::integral_constant<int, 4>{}, c);
-        step(std::integral_constant<int, 5>{}, c);
-        step(std::integral_constant<int, 6>{}, c);
-        step(std::integral_constant<int, 7>{}, c);
-        step(std::integral_constant<int, 8>{}, c);
+        if constexpr (KS == 3) {
+            step(std::integral_constant<int, 4>{}, c);
+            step(std::integral_constant<int, 5>{}, c);
+            step(std::integral_constant<int, 6>{}, c);
+            step(std::integral_constant<int, 7>{}, c);
+            step(std::integral_constant<int, 8>{}, c);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the masked tail requests before the epilogue
 
-    lb_gemm_tile_epilogue_rows<TM, TN, false>(p, acc, [&](int i) { return mrow[i]; },
-                                              n0 + wave_n * (BN / 2) + 4 * g, 0);
+    if constexpr (KS == 2) {
+        LbGemmParams q = p;                             // this block's parity drives the scatter of the shared epilogue
+        q.scatter = 1;
+        q.sc_py = par_y;
+        q.sc_px = par_x;
+        lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mrow[i]; }, n0 + wave_n * (BN / 2) + 4 * g, 0);
+    } else {
+        lb_gemm_tile_epilogue_rows<TM, TN, false>(p, acc, [&](int i) { return mrow[i]; },
+                                                  n0 + wave_n * (BN / 2) + 4 * g, 0);
+    }
 }
 
-template <int BN, int TW>
+template <int BN, int TW, int KS = 3>
 static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
     constexpr int TH = 256 / TW;
-    constexpr int HRP = (((TH + 2) * (TW + 2) + 7) / 8) * 8;
+    constexpr int HRP = (((TH + KS - 1) * (TW + KS - 1) + 7) / 8) * 8;
     constexpr int SMEM = (2 * HRP * 64 + 4 * BN * 64) * (int)sizeof(f16);
     static bool allowed = false;
     if (!allowed) {                                     // (first call happens at record time, outside any capture)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW, KS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         allowed = true;
     }
-    const long tiles = (long)(p.M / (p.Hin * p.Win)) * (p.Hin / TH) * (p.Win / TW);
+    const long tiles = (long)(p.M / (p.Hin * p.Win)) * (p.Hin / TH) * (p.Win / TW) * (KS == 2 ? 4 : 1);
     const long nblk = tiles * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW>), dim3((unsigned)nblk), dim3(512), SMEM, stream, p);
-    return lb_check_launch("lb_conv3x3_halo_f16");
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS>), dim3((unsigned)nblk), dim3(512), SMEM, stream, p);
+    return lb_check_launch(KS == 2 ? "lb_upconv2x_halo_f16" : "lb_conv3x3_halo_f16");
+}
+
+// Sub-pixel upsampler (scatter == 2): 0 = not eligible, else the tile width
+int lb_upconv_halo_eligible(const LbGemmParams& p) {
+    if (!p.conv || p.scatter != 2 || p.KH != 2 || p.KW != 2 || p.stride != 1 || p.ups) return 0;
+    if (p.Hout != p.Hin || p.Wout != p.Win || p.Cin % 64 != 0 || p.K != 4 * p.Cin) return 0;
+    if (p.zero_page == nullptr || (p.flags & (LB_GEMM_GEGLU | LB_GEMM_TRANS_OUT)) || p.N % 4 != 0 || p.residual != nullptr) return 0;
+    if (p.M % (p.Hin * p.Win) != 0) return 0;
+    if (p.Win % 32 == 0 && p.Hin % 8 == 0) return 32;
+    if (p.Win % 16 == 0 && p.Hin % 16 == 0) return 16;
+    return 0;
+}
+
+int lb_upconv_halo_launch(LbGemmParams p, hipStream_t stream) {
+    if (p.alpha == 0.f) p.alpha = 1.f;
+    p.splitk = 1;
+    return lb_upconv_halo_eligible(p) == 32 ? launch_halo<128, 32, 2>(p, stream) : launch_halo<128, 16, 2>(p, stream);
+}
+
+// nearest-2x upsample + 3x3 conv as ONE launch: W = [4][N][ldw] stacked sub-pixel kernels (parity py*2+px), C = [B][2H][2W][ldc]
+extern "C" int lb_upconv2x_halo_f16(const LbGemmParams* pp, void* stream) {
+    LbGemmParams p = *pp;
+    LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_upconv2x_halo_f16: empty problem");
+    LB_REQUIRE(lb_upconv_halo_eligible(p) != 0,
+               "lb_upconv2x_halo_f16: needs scatter = 2, KH = KW = 2, stride 1, Cin % 64 == 0, W % 16 == 0, zero page, no residual");
+    LB_REQUIRE(p.ldw % 8 == 0 && p.ldx % 8 == 0 && p.ldc % 4 == 0, "lb_upconv2x_halo_f16: ldw / ldx multiples of 8, ldc multiple of 4");
+    LB_DISPATCH("lb_upconv2x_halo_f16", lb_upconv_halo_launch(p, s));
 }
 
 // 0 = not eligible, else the tile width the halo kernel would use

@@ -327,6 +327,8 @@ extern "C" void lb_gemm_set_policy(int disable_mask) { g_policy_off = disable_ma
 int lb_conv3x3_halo_eligible(const LbGemmParams& p);
 long lb_conv3x3_halo_blocks(const LbGemmParams& p);
 int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream);
+int lb_upconv_halo_eligible(const LbGemmParams& p);
+int lb_upconv_halo_launch(LbGemmParams p, hipStream_t stream);
 #define LB_HALO_MIN_BLOCKS 96
 static int g_halo = 1;
 extern "C" void lb_gemm_set_halo(int mode) { g_halo = mode; }
@@ -505,6 +507,10 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(p.lda >= p.K && !(p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: LB_GEMM_LN_A normalises whole rows of A");
     }
     if (p.alpha == 0.f) p.alpha = 1.f;
+    if (p.scatter == 2) {       // all four sub-pixel parities in one launch: only the halo kernel implements it
+        LB_REQUIRE(lb_upconv_halo_eligible(p) != 0, "lb_gemm_f16: scatter = 2 needs Cin % 64 == 0, W % 16 == 0, stacked [4][N][K] weights");
+        LB_DISPATCH("lb_upconv2x_halo_f16", lb_upconv_halo_launch(p, s));
+    }
     if (use_halo(p)) LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
     int tile = 0, splitk = 1;
     long nblk = 0;

@@ -73,6 +73,7 @@ SIGNATURES = {
     "lb_gemm_set_policy": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
+    "lb_upconv2x_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_gemm_plan": (_i, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
     "lb_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),

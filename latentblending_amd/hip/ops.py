@@ -172,7 +172,10 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
         p.KH, p.KW, p.stride, p.pad, p.ups, p.ldx = kh, kw, st, pad, ups, A.stride(2)
         out_shape = (B, hout, wout)
         if "parity" in conv:                          # sub-pixel upsampling conv: caller supplies `out`
-            p.scatter, p.sc_py, p.sc_px = 1, int(conv["parity"][0]), int(conv["parity"][1])
+            if conv["parity"] == "all":
+                p.scatter = 2                         # W = parity 0 of a stacked [4][N][K] tensor
+            else:
+                p.scatter, p.sc_py, p.sc_px = 1, int(conv["parity"][0]), int(conv["parity"][1])
             hout, wout = H, Wd
             Mv = B * H * Wd
             p.Hout, p.Wout = H, Wd

@@ -179,7 +179,9 @@ class Emitter:
             p.conv = 1
             for k in ("Hin", "Win", "Cin", "Hout", "Wout", "KH", "KW", "stride", "pad", "ups", "ldx"):
                 setattr(p, k, int(conv[k]))
-            if "parity" in conv:                       # sub-pixel upsampling conv
+            if conv.get("parity") == "all":            # all four sub-pixel convs in ONE halo-kernel launch (W stacked [4][N][K])
+                p.scatter = 2
+            elif "parity" in conv:                     # one sub-pixel upsampling conv
                 p.scatter, p.sc_py, p.sc_px = 1, int(conv["parity"][0]), int(conv["parity"][1])
         else:
             p.lda = lda if lda is not None else K
@@ -195,9 +197,17 @@ class Emitter:
         if splitk and not (flags & lib.GEMM_GEGLU) and ln is None:
             p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())
-        self.gemm_log.append({"M": M, "N": N, "K": K, "flops": 2.0 * M * N * K, "conv": conv is not None,
-                              "bytes": 2.0 * (N * K + M * n_out) + (2.0 * M * K if conv is None else 0.0)})
+        mult = 4.0 if p.scatter == 2 else 1.0          # (four parities: four times the rows, weights and outputs)
+        self.gemm_log.append({"M": M, "N": N, "K": K, "flops": mult * 2.0 * M * N * K, "conv": conv is not None,
+                              "bytes": mult * 2.0 * (N * K + M * n_out) + (2.0 * M * K if conv is None else 0.0)})
         return out
+
+    @staticmethod
+    def upconv_one_launch(B: int, H: int, W: int, cin: int, cout: int) -> bool:
+        """The halo kernel's sub-pixel form takes this upsampler conv in one launch (else: four implicit-GEMM launches)."""
+        shape_ok = cin % 64 == 0 and ((W % 32 == 0 and H % 8 == 0) or (W % 16 == 0 and H % 16 == 0))
+        blocks = B * (H * W // 256) * 4 * ((cout + 127) // 128)
+        return shape_ok and blocks >= 96
 
     def groupnorm(self, x: torch.Tensor, out: torch.Tensor, gamma, beta, *, B: int, HW: int, C_: int,
                   eps: float, silu: bool, groups: int = 32, ldx: Optional[int] = None):

@@ -102,8 +102,11 @@ class NativeUNet:
         """Upsampler conv (nearest-2x, then 3x3) stored as four 2x2 sub-pixel kernels (4/9 of the FLOPs)."""
         from ..hip.ops import subpixel_upsample_weights
         w = pv.weight(name + ".weight", (c, c, 3, 3), c * 9, 1.0)
-        for (py, px), k in subpixel_upsample_weights(w, _pad(c, 8)).items():
+        subs = subpixel_upsample_weights(w, _pad(c, 8))
+        for (py, px), k in subs.items():
             self.w[f"{name}.weight.sub{py}{px}"] = k.to(self.device)
+        # the same four kernels stacked [4][N][4 Cin] (parity py*2+px) for the one-launch halo form
+        self.w[f"{name}.weight.sub4"] = torch.stack([subs[(0, 0)], subs[(0, 1)], subs[(1, 0)], subs[(1, 1)]]).to(self.device).contiguous()
         self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
 
     def _norm(self, pv, name, c, keep_host=False):
@@ -289,6 +292,10 @@ class UNetProgram:
         """nearest-2x upsample + 3x3 conv as four sub-pixel 2x2 convs scattered into the 2H x 2W output."""
         em, w = self.em, self.net.w
         out = self.arena.alloc((B, 2 * H, 2 * W, c))
+        if em.upconv_one_launch(B, H, W, c, c):
+            em.gemm(x, w[f"{name}.weight.sub4"][0], out, M=B * H * W, bias=w[name + ".bias"], ldc=c,
+                    conv=dict(Hin=H, Win=W, Cin=c, Hout=H, Wout=W, KH=2, KW=2, stride=1, pad=0, ups=0, ldx=c, parity="all"))
+            return out, 2 * H, 2 * W
         for py in (0, 1):
             for px in (0, 1):
                 em.gemm(x, w[f"{name}.weight.sub{py}{px}"], out, M=B * H * W, bias=w[name + ".bias"], ldc=c,

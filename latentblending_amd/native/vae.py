@@ -71,8 +71,11 @@ class NativeVAEDecoder:
     def _upconv(self, pv, name, c):
         from ..hip.ops import subpixel_upsample_weights
         w = pv.weight(name + ".weight", (c, c, 3, 3), c * 9, 1.0)
-        for (py, px), k in subpixel_upsample_weights(w, _pad(c, 8)).items():
+        subs = subpixel_upsample_weights(w, _pad(c, 8))
+        for (py, px), k in subs.items():
             self.w[f"{name}.weight.sub{py}{px}"] = k.to(self.device)
+        # the same four kernels stacked [4][N][4 Cin] (parity py*2+px) for the one-launch halo form
+        self.w[f"{name}.weight.sub4"] = torch.stack([subs[(0, 0)], subs[(0, 1)], subs[(1, 0)], subs[(1, 1)]]).to(self.device).contiguous()
         self.w[name + ".bias"] = self._dev(pv.bias(name + ".bias", c), F32)
 
     def _norm(self, pv, name, c):
@@ -248,7 +251,14 @@ class VAEProgram:
                 h16, owned = self._stream_as_operand(h, B, side, side, c)
                 name = f"decoder.up_blocks.{ui}.upsamplers.0.conv"
                 up = ar.alloc((B, 2 * side, 2 * side, c), F16 if sc else F32)
-                for py in (0, 1):           # sub-pixel form of upsample+conv: four 2x2 convs on the low-res grid
+                one = em.upconv_one_launch(B, side, side, c, c)
+                if one:                     # all four sub-pixel convs in ONE launch of the halo kernel
+                    em.gemm(h16, w[f"{name}.weight.sub4"][0], up, M=B * side * side,
+                            bias=w[name + (".bias_s" if sc else ".bias")], ldc=c,
+                            flags=0 if sc else lib.GEMM_OUT_F32, alpha=1.0 if sc else 1.0 / STREAM_SCALE,
+                            conv=dict(Hin=side, Win=side, Cin=c, Hout=side, Wout=side, KH=2, KW=2, stride=1, pad=0,
+                                      ups=0, ldx=c, parity="all"))
+                for py in (() if one else (0, 1)):           # else: four 2x2 convs on the low-res grid
                     for px in (0, 1):
                         em.gemm(h16, w[f"{name}.weight.sub{py}{px}"], up, M=B * side * side,
                                 bias=w[name + (".bias_s" if sc else ".bias")], ldc=c,

@@ -601,6 +601,27 @@ def test_subpixel_upsample_conv(variant, results_log):
     check_close(results_log, f"subpixel_upconv_v{variant}", out, ref, rel=3e-3)
 
 
+@pytest.mark.parametrize("B,H,Wd,Cin,Cout", [(2, 16, 16, 64, 64), (1, 8, 32, 128, 320), (3, 32, 32, 192, 128), (2, 16, 48, 64, 200)])
+def test_subpixel_upsample_conv_one_launch(B, H, Wd, Cin, Cout, results_log):
+    """The same upsample+conv as ONE launch of the halo-tile kernel's 2x2 form (scatter = 2, stacked weights): must equal
+    both the fp32 torch reference and, bit for bit in fp16, nothing less than the four-launch implicit-GEMM form's tolerance."""
+    o, l = ops(), lib()
+    x, w = rnd(B, Cin, H, Wd, seed=190), rnd(Cout, Cin, 3, 3, seed=191, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=192, dtype=torch.float32)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    subs = o.subpixel_upsample_weights(w)
+    w4 = torch.stack([subs[(0, 0)], subs[(0, 1)], subs[(1, 0)], subs[(1, 1)]]).to(DEV).contiguous()
+    out = torch.full((B, 2 * H, 2 * Wd, Cout), float("nan"), dtype=torch.float16, device=DEV)
+    o.gemm(xn, w4[0], bias=bias.to(DEV), out=out, conv=dict(KH=2, KW=2, stride=1, pad=0, parity="all"))
+    assert torch.isfinite(out).all(), "one-launch sub-pixel conv left output pixels unwritten"
+    check_close(results_log, f"subpixel_upconv_halo_{B}x{H}x{Wd}x{Cin}x{Cout}", out, ref, rel=3e-3)
+    four = torch.zeros_like(out)
+    for (py, px), k in subs.items():
+        o.gemm(xn, k.to(DEV), bias=bias.to(DEV), out=four, conv=dict(KH=2, KW=2, stride=1, pad=0, parity=(py, px)))
+    assert (out.float() - four.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
 # ------------------------------------------------------------------ halo-tile 3x3 conv
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 128), (1, 64, 64, 128, 320), (3, 16, 16, 192, 132), (1, 8, 96, 64, 64),
                                   (2, 48, 16, 128, 256)])
