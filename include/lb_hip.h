@@ -129,6 +129,12 @@ int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /
  * (lb_gemm_plan reports tile code 6); lb_gemm_set_halo: 0 = never, 1 = when the halo grid fills the chip
  * (default), 2 = whenever eligible. */
 int lb_conv3x3_halo_f16(const LbGemmParams* params, void* stream);
+/* Tuning: 1 (default) = persistent blocks (one per CU) whose operand request streams run across tile boundaries;
+ * 0 = one (tile, channel block) item per block. */
+void lb_conv_halo_set_persistent(int on);
+/* Timing studies only (tools/halo_study.py): bit 0 skip the epilogue, bit 1 / bit 2 halo / weight requests from the zero
+ * page.  Any non-zero value makes the results wrong by construction; default 0. */
+void lb_conv_halo_set_study(int bits);
 /* "nearest-2x upsample, then 3x3 conv" (UNet / VAE upsamplers) as ONE launch of the halo-tile kernel in its 2x2 sub-pixel
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
@@ -140,6 +146,9 @@ void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = dir
  *      from diffusers_holder.py:336 and :135) ------------------------------------------- */
 /* x: [B][HW][ldx] fp16 (or fp32 when x_is_f32); y: [B][HW][ldy] fp16 = GN(x)*gamma+beta, then
  * SiLU when `silu`.  workspace: lb_groupnorm_workspace_bytes(B, groups). */
+/* Experiment knob: input bytes per statistics+apply pair (sample groups sized for the Infinity Cache); default 0 = one
+ * pair over the whole batch, which measured faster at every group size (profiles/r02_groupnorm_l3.txt). */
+void lb_groupnorm_set_l3_chunk(long bytes);
 long lb_groupnorm_workspace_bytes(int B, int groups);
 int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace,
                       int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,

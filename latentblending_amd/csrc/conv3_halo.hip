@@ -77,49 +77,62 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int g = lane >> 4, l16 = lane & 15;
 
-    // ---- block -> (image b, tile ty, tx, channel block) ; XCD-contiguous, channel block fastest ----
+    // ---- work items: (pixel tile [, parity], channel block), channel block fastest; XCD-contiguous block ids ------
+    // PERSISTENT form: the grid is G <= #CUs blocks (one per CU: the LDS footprint allows no more) and block `bid`
+    // walks items bid, bid + G, bid + 2G, ...  G is a multiple of the channel blocks (x4 parities for KS == 2), so a
+    // block keeps ONE weight slab (block_n, parity) for its whole life and only the pixel tile changes.  The request
+    // streams do not stop at a tile boundary: during the last chunk of tile k the "next halo" is chunk 0 of tile k+1
+    // and W(step + 3) wraps to its first taps, so the epilogue of tile k (global stores, no LDS) runs with the next
+    // tile's operands already in flight - a block of the one-item-per-block form paid launch + first-halo latency +
+    // store drain (measured ~14 us, against 11 us of MFMA work for an 18-step Cin = 128 tile) once per tile.
+    // With gridDim.x == number of items the same code is the one-item-per-block form.
     const int n_blocks = (p.N + BN - 1) / BN;
     const int tiles_x = p.Win / TW, tiles_y = p.Hin / TH;
+    const int n_items = (p.M / (p.Hin * p.Win)) * tiles_x * tiles_y * (KS == 2 ? 4 : 1) * n_blocks;
+    const int G = gridDim.x;
     int bid = blockIdx.x;
     {
-        const int nwg = gridDim.x;
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        const int q = G / 8, r = G % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int block_n = bid % n_blocks;
-    int tile = bid / n_blocks;
-    int par_y = 0, par_x = 0;                           // output parity of a sub-pixel block
-    if (KS == 2) {
-        par_x = tile & 1;
-        par_y = (tile >> 1) & 1;
-        tile >>= 2;
-    }
-    const int tx = tile % tiles_x;
-    tile /= tiles_x;
-    const int ty = tile % tiles_y;
-    const int b = tile / tiles_y;
+    const int par_x = KS == 2 ? (bid / n_blocks) & 1 : 0;          // output parity of a sub-pixel block
+    const int par_y = KS == 2 ? ((bid / n_blocks) >> 1) & 1 : 0;
     const int n0 = block_n * BN;
-    const int y0 = ty * TH, x0 = tx * TW;
     const int org_y = KS == 3 ? 1 : 1 - par_y, org_x = KS == 3 ? 1 : 1 - par_x;     // halo row 0 / col 0 = pixel (y0 - org_y, x0 - org_x)
     const lb_half* Wp = p.W + (KS == 2 ? (long)(par_y * 2 + par_x) * p.N * p.ldw : 0);
     const int nchunks = p.Cin / 64;
     const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
+
+    struct TileAt { int b, y0, x0; };
+    auto tile_of = [&](int item) {                      // item -> image and tile origin (block-uniform: scalar registers)
+        int tile = item / n_blocks;
+        if (KS == 2) tile >>= 2;
+        TileAt t;
+        t.x0 = (tile % tiles_x) * TW;
+        tile /= tiles_x;
+        t.y0 = (tile % tiles_y) * TH;
+        t.b = tile / tiles_y;
+        return t;
+    };
 
     // ---- loader state -------------------------------------------------------------------------------
     // halo: wave instruction j (0..5) covers row group gidx(j); lane (r8 = lane>>3, slot = lane&7) fetches
     // logical chunk slot ^ r8 of halo row gidx*8 + r8
     const int r8 = lane >> 3;
     const int cl = (lane & 7) ^ r8;
-    long h_off[NR];                                     // element offset of the pixel (chunk 0), -1 = zero page
+    long h_off[NR];                                     // element offset of the pixel (chunk 0) in the tile being REQUESTED, -1 = zero page
+    auto set_halo_offsets = [&](const TileAt& t, bool exists) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const int gidx = j * 8 + wave;
-        const int row = gidx * 8 + r8;
-        const int hy = row / HWP, hx = row - hy * HWP;
-        const int y = y0 + hy - org_y, x = x0 + hx - org_x;
-        const bool ok = (j < NR - 1 || wave < EXTRA) && row < HR && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
-        h_off[j] = ok ? ((long)(b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 : -1;
-    }
+        for (int j = 0; j < NR; ++j) {
+            const int gidx = j * 8 + wave;
+            const int row = gidx * 8 + r8;
+            const int hy = row / HWP, hx = row - hy * HWP;
+            const int y = t.y0 + hy - org_y, x = t.x0 + hx - org_x;
+            const bool ok = exists && (j < NR - 1 || wave < EXTRA) && row < HR && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+            h_off[j] = ok ? ((long)(t.b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 : -1;
+        }
+    };
     // weights: thread stages rows (tid>>3) + 64 i of the BN x 64 tile
     long w_off[WI];
 #pragma unroll
@@ -128,15 +141,15 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         w_off[i] = n < p.N ? (long)n * p.ldw + cl * 8 : -1;
     }
 
-    auto issue_halo = [&](int j, int chunk) {           // one wave instruction of the halo of `chunk`
-        const bool live = h_off[j] >= 0 && chunk < nchunks;
-        const lb_half* src = live ? p.A + h_off[j] + (long)chunk * 64 : zero;
+    const int study = p.reserved_;                      // timing studies only (lb_conv_halo_set_study): 1 no epilogue, 2 halo from the zero page, 4 weights from the zero page
+    auto issue_halo = [&](int j, int src_chunk, int buf) {   // one wave instruction of a halo (of the tile h_off describes)
+        const lb_half* src = h_off[j] >= 0 && !(study & 2) ? p.A + h_off[j] + (long)src_chunk * 64 : zero;
         const int gidx = j * 8 + wave;
-        f16* dst = halo0 + (chunk & 1) * (HRP * 64) + gidx * 8 * 64;
+        f16* dst = halo0 + buf * (HRP * 64) + gidx * 8 * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
-    auto issue_weight = [&](int i, int chunk, int tap, int slot) {
-        const bool live = w_off[i] >= 0 && chunk < nchunks;
+    auto issue_weight = [&](int i, int chunk, bool exists, int tap, int slot) {
+        const bool live = w_off[i] >= 0 && exists && !(study & 4);
         const lb_half* src = live ? Wp + w_off[i] + (long)tap * p.Cin + (long)chunk * 64 : zero;
         f16* dst = wring + slot * (BN * 64) + (wave * 8 + i * 64) * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
@@ -144,13 +157,13 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
 
     // ---- consumer state -----------------------------------------------------------------------------
     int hbase[TM];                                      // halo row of tap (0, 0) of the lane's pixel i
-    int mrow[TM];                                       // global output pixel index
+    int mloc[TM];                                       // the pixel's offset from the tile origin, in image pixels
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = wave_m * 64 + i * 16 + l16;
         const int py = m / TW, px = m - py * TW;
         hbase[i] = py * HWP + px;
-        mrow[i] = (b * p.Hin + y0 + py) * p.Win + x0 + px;     // (low-res pixel index; the epilogue scatters it for KS == 2)
+        mloc[i] = py * p.Win + px;
     }
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -179,79 +192,125 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: halo of chunk 0, weight tiles of steps 0..2 ----------------------------------------
+    // ---- prologue: halo of chunk 0 of the first tile, weight tiles of steps 0..2 ------------------------
+    int item = bid;
+    TileAt cur = tile_of(item);
+    set_halo_offsets(cur, true);
 #pragma unroll
     for (int j = 0; j < NR; ++j)
-        if (j < NR - 1 || wave < EXTRA) issue_halo(j, 0);
+        if (j < NR - 1 || wave < EXTRA) issue_halo(j, 0, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < WI; ++i) issue_weight(i, 0, t, t);
+        for (int i = 0; i < WI; ++i) issue_weight(i, 0, true, t, t);
 
-    // one step; TAP is a compile-time constant so that every count below is an immediate
-    auto step = [&](auto tap_c, int c) {
+    // one step; TAP is a compile-time constant so that every count below is an immediate.  c = chunk within the tile,
+    // cc = chunks since the block started (halo buffer / weight slot parity run on across tiles), more = another tile follows
+    auto step = [&](auto tap_c, int c, int cc, bool more) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr int P1 = (TAP + NTAP - 1) % NTAP, P2 = (TAP + NTAP - 2) % NTAP;          // taps of the two previous steps
         constexpr int CNT = (2 + halo_full_rounds_in_tap<KS, NR, P1>()) + (2 + halo_full_rounds_in_tap<KS, NR, P2>());
         halo_wait_barrier<CNT>();
-        const int slot = KS == 3 ? ((c + TAP) & 3) : TAP;   // (NTAP c + TAP) mod 4
-        const f16* hb = halo0 + (c & 1) * (HRP * 64);
+        const int slot = KS == 3 ? ((cc + TAP) & 3) : TAP;   // (NTAP cc + TAP) mod 4
+        const f16* hb = halo0 + (cc & 1) * (HRP * 64);
         const f16* wb = wring + slot * (BN * 64);
         constexpr int KY = TAP / KS, KX = TAP % KS;
         // the tap's row shift goes through an opaque register: the swizzled fragment addresses of all taps are
         // loop-invariant, and hoisting them out of the chunk loop costs more registers than the file has
         int shift = KY * HWP + KX;
         asm volatile("" : "+v"(shift));
-        // requests of this step: rounds of the halo of chunk c+1 scheduled here, then W(step + 3)
+        // requests of this step: rounds of the NEXT halo scheduled here (chunk c+1, or chunk 0 of the next tile: h_off
+        // was re-pointed at the start of the tile's last chunk), then W(step + 3) (wrapping into the next tile likewise)
+        const bool last = c + 1 == nchunks;
+        const int hc = last ? 0 : c + 1, hbuf = (cc + 1) & 1;
         constexpr int TAP3 = (TAP + 3) % NTAP;
-        const int c3 = c + (TAP + 3) / NTAP;
+        const bool wrap = (TAP + 3 >= NTAP) && last;
+        const int c3 = wrap ? 0 : c + (TAP + 3) / NTAP;
+        const bool w_exists = !wrap || more;
         const int slot3 = (slot + 3) & 3;
         f16x8 a0[TM], w0[TN], a1[TM], w1[TN];
         read_frags(hb, wb, shift, 0, a0, w0);
-        if constexpr (HaloSched<KS, 0>::tap == TAP) issue_halo(0, c + 1);
-        if constexpr (NR > 2 && HaloSched<KS, 1>::tap == TAP) issue_halo(1, c + 1);
-        if constexpr (NR > 3 && HaloSched<KS, 2>::tap == TAP) issue_halo(2, c + 1);
-        if constexpr (NR > 4 && HaloSched<KS, 3>::tap == TAP) { if (NR - 1 > 3 || wave < EXTRA) issue_halo(3, c + 1); }
-        if constexpr (NR > 4 && HaloSched<KS, 4>::tap == TAP) { if (NR - 1 > 4 || wave < EXTRA) issue_halo(4, c + 1); }
-        if constexpr (NR > 5 && HaloSched<KS, 5>::tap == TAP) { if (wave < EXTRA) issue_halo(5, c + 1); }
+        if constexpr (HaloSched<KS, 0>::tap == TAP) issue_halo(0, hc, hbuf);
+        if constexpr (NR > 2 && HaloSched<KS, 1>::tap == TAP) issue_halo(1, hc, hbuf);
+        if constexpr (NR > 3 && HaloSched<KS, 2>::tap == TAP) issue_halo(2, hc, hbuf);
+        if constexpr (NR > 4 && HaloSched<KS, 3>::tap == TAP) { if (NR - 1 > 3 || wave < EXTRA) issue_halo(3, hc, hbuf); }
+        if constexpr (NR > 4 && HaloSched<KS, 4>::tap == TAP) { if (NR - 1 > 4 || wave < EXTRA) issue_halo(4, hc, hbuf); }
+        if constexpr (NR > 5 && HaloSched<KS, 5>::tap == TAP) { if (wave < EXTRA) issue_halo(5, hc, hbuf); }
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a0, w0, 0, TM / 2);
         read_frags(hb, wb, shift, 1, a1, w1);
         __builtin_amdgcn_sched_barrier(0);
-        issue_weight(0, c3, TAP3, slot3);
+        issue_weight(0, c3, w_exists, TAP3, slot3);
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a0, w0, TM / 2, TM);
         __builtin_amdgcn_sched_barrier(0);
-        issue_weight(1, c3, TAP3, slot3);
+        issue_weight(1, c3, w_exists, TAP3, slot3);
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a1, w1, 0, TM);
     };
 
-    for (int c = 0; c < nchunks; ++c) {
-        step(std::integral_constant<int, 0>{}, c);
-        step(std::integral_constant<int, 1>{}, c);
-        step(std::integral_constant<int, 2>{}, c);
-        step(std::integral_constant<int, 3>{}, c);
-        if constexpr (KS == 3) {
-            step(std::integral_constant<int, 4>{}, c);
-            step(std::integral_constant<int, 5>{}, c);
-            step(std::integral_constant<int, 6>{}, c);
-            step(std::integral_constant<int, 7>{}, c);
-            step(std::integral_constant<int, 8>{}, c);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // drain the masked tail requests before the epilogue
-
+    LbGemmParams q = p;                                 // (KS == 2: this block's parity drives the scatter of the shared epilogue)
     if constexpr (KS == 2) {
-        LbGemmParams q = p;                             // this block's parity drives the scatter of the shared epilogue
         q.scatter = 1;
         q.sc_py = par_y;
         q.sc_px = par_x;
-        lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mrow[i]; }, n0 + wave_n * (BN / 2) + 4 * g, 0);
-    } else {
-        lb_gemm_tile_epilogue_rows<TM, TN, false>(p, acc, [&](int i) { return mrow[i]; },
-                                                  n0 + wave_n * (BN / 2) + 4 * g, 0);
     }
+
+    int cc = 0;
+    for (;;) {
+        const int next_item = item + G;
+        const bool more = next_item < n_items;
+        const TileAt nxt = tile_of(more ? next_item : item);
+        for (int c = 0; c < nchunks; ++c, ++cc) {
+            if (c + 1 == nchunks) set_halo_offsets(nxt, more);      // this tile's halos are all requested: aim at the next tile
+            step(std::integral_constant<int, 0>{}, c, cc, more);
+            step(std::integral_constant<int, 1>{}, c, cc, more);
+            step(std::integral_constant<int, 2>{}, c, cc, more);
+            step(std::integral_constant<int, 3>{}, c, cc, more);
+            if constexpr (KS == 3) {
+                step(std::integral_constant<int, 4>{}, c, cc, more);
+                step(std::integral_constant<int, 5>{}, c, cc, more);
+                step(std::integral_constant<int, 6>{}, c, cc, more);
+                step(std::integral_constant<int, 7>{}, c, cc, more);
+                step(std::integral_constant<int, 8>{}, c, cc, more);
+            }
+        }
+        // epilogue of this tile (registers -> global memory; the next tile's first operands are in flight meanwhile)
+        const int mbase = (cur.b * p.Hin + cur.y0) * p.Win + cur.x0;    // (low-res pixel index; the epilogue scatters it for KS == 2)
+        // (the lane's first column goes through an opaque register: bias vectors, column masks and output offsets are
+        // tile-invariant, and the compiler would otherwise hoist them out of the tile loop and hold ~30 registers
+        // across the MFMA loop - which it then spills around this epilogue)
+        int col0 = n0 + wave_n * (BN / 2) + 4 * g;
+        asm volatile("" : "+v"(col0));
+        if (!(study & 1)) lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
+        else if (acc[0][0][0] == 12345.678f) *(float*)p.C = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];   // (keeps the MFMAs alive)
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        item = next_item;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the masked tail requests still target this block's LDS: drain before exit
+}
+
+// 1 (default): persistent blocks with the request streams running across tile boundaries; 0: one item per block
+static int g_halo_persistent = 1;
+static int g_halo_study = 0;
+extern "C" void lb_conv_halo_set_persistent(int on) { g_halo_persistent = on; }
+// Timing studies (tools/halo_study.py): bit 0 skip the epilogue, bit 1 halo loads from the zero page, bit 2 weight
+// loads from the zero page.  Results are then WRONG by construction; 0 (default) = the real kernel.
+extern "C" void lb_conv_halo_set_study(int bits) { g_halo_study = bits; }
+static int halo_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                ? prop.multiProcessorCount : 256;
+    }
+    return n;
 }
 
 template <int BN, int TW, int KS = 3>
@@ -266,8 +325,17 @@ static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
         allowed = true;
     }
     const long tiles = (long)(p.M / (p.Hin * p.Win)) * (p.Hin / TH) * (p.Win / TW) * (KS == 2 ? 4 : 1);
-    const long nblk = tiles * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS>), dim3((unsigned)nblk), dim3(512), SMEM, stream, p);
+    const int n_blocks = (p.N + BN - 1) / BN;
+    const long nblk = tiles * n_blocks;
+    LB_REQUIRE(nblk < (1l << 30), "halo conv: too many tiles for one launch");
+    // persistent grid: the largest multiple of the weight-slab period (channel blocks, x4 parities) that fits the CUs
+    const int period = n_blocks * (KS == 2 ? 4 : 1);
+    long grid = nblk;
+    if (g_halo_persistent && period <= halo_num_cus() && nblk > halo_num_cus())
+        grid = (long)(halo_num_cus() / period) * period;
+    LbGemmParams pk = p;
+    pk.reserved_ = g_halo_study;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS>), dim3((unsigned)grid), dim3(512), SMEM, stream, pk);
     return lb_check_launch(KS == 2 ? "lb_upconv2x_halo_f16" : "lb_conv3x3_halo_f16");
 }
 

@@ -240,6 +240,34 @@ static int groupnorm_impl(const void* x, void* y, const float* gamma, const floa
     return lb_check_launch("lb_groupnorm_nhwc(apply)");
 }
 
+// Samples per statistics+apply pair (experiment, OFF by default).  The apply pass re-reads what the statistics pass just
+// read; the idea was to walk a big batch (VAE decode at 512^2) in sample groups that fit the 256 MiB Infinity Cache so
+// that the second read never reaches HBM.  Measured (profiles/r02_groupnorm_l3.txt): every group size from 32 to 192 MiB
+// is SLOWER than one pair over the whole batch (17x512x512x128: 647 us whole batch, 784-1045 us grouped) - the smaller
+// launches lose more memory-level parallelism than the cache returns.  0 = whole batch.
+static long g_gn_l3_bytes = 0;
+extern "C" void lb_groupnorm_set_l3_chunk(long bytes) { g_gn_l3_bytes = bytes; }
+
+static int groupnorm_chunked(const void* x, void* y, const float* gamma, const float* beta, void* workspace,
+                             int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,
+                             int x_is_f32, hipStream_t stream) {
+    const long elt = x_is_f32 ? 4 : 2;
+    const long sample_bytes = (long)HW * ldx * elt;
+    long nb = B;
+    if (g_gn_l3_bytes > 0 && sample_bytes * B > g_gn_l3_bytes) {
+        nb = g_gn_l3_bytes / sample_bytes;
+        if (nb < 1) nb = 1;
+    }
+    for (long b0 = 0; b0 < B; b0 += nb) {
+        const int bn = (int)(B - b0 < nb ? B - b0 : nb);
+        const int rc = groupnorm_impl((const char*)x + b0 * sample_bytes, (f16*)y + b0 * (long)HW * ldy, gamma, beta,
+                                      (double*)workspace + b0 * GN_MAX_CHUNKS * groups * 2, bn, HW, C, ldx, ldy,
+                                      groups, eps, silu, x_is_f32, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta,
                                  void* workspace, int B, int HW, int C, int ldx, int ldy, int groups,
                                  float eps, int silu, int x_is_f32, void* stream) {
@@ -247,8 +275,8 @@ extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, con
     LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "lb_groupnorm_nhwc: C/ld multiple of 8");
     LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_nhwc: groups");
     LB_REQUIRE(C <= 4096, "lb_groupnorm_nhwc: C <= 4096");
-    LB_DISPATCH("lb_groupnorm_nhwc", groupnorm_impl(x, y, gamma, beta, workspace, B, HW, C, ldx, ldy, groups,
-                                                    eps, silu, x_is_f32, s));
+    LB_DISPATCH("lb_groupnorm_nhwc", groupnorm_chunked(x, y, gamma, beta, workspace, B, HW, C, ldx, ldy, groups,
+                                                       eps, silu, x_is_f32, s));
 }
 
 // ------------------------------------------------------------------------------------------

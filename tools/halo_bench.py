@@ -38,12 +38,15 @@ def main():
         p.partial = ws.data_ptr() if small else None
         flops = 2.0 * M * N * K
         auto = time_variant(p, 0, 0, 0)
+        lib.api.lb_conv_halo_set_persistent(0)
+        halo1 = time_variant(p, 0, 0, 0, halo=True)
+        lib.api.lb_conv_halo_set_persistent(1)
         halo = time_variant(p, 0, 0, 0, halo=True)
-        row = {"shape": f"B{B} {H}x{H} {C1}->{C2}", "auto_us": auto, "halo_us": halo, "auto_TF": flops / auto / 1e6,
-               "halo_TF": flops / halo / 1e6}
+        row = {"shape": f"B{B} {H}x{H} {C1}->{C2}", "auto_us": auto, "halo_us": halo, "halo_one_item_us": halo1,
+               "auto_TF": flops / auto / 1e6, "halo_TF": flops / halo / 1e6, "halo_one_item_TF": flops / halo1 / 1e6}
         rows.append(row)
-        print(f"{row['shape']:24s} auto {auto:9.1f} us {row['auto_TF']:6.0f} TF | halo {halo:9.1f} us {row['halo_TF']:6.0f} TF "
-              f"| x{auto / halo:.2f}", flush=True)
+        print(f"{row['shape']:24s} implicit GEMM {auto:9.1f} us {row['auto_TF']:6.0f} TF | halo, one item/block {halo1:9.1f} us "
+              f"{row['halo_one_item_TF']:6.0f} TF | halo, persistent {halo:9.1f} us {row['halo_TF']:6.0f} TF | x{auto / halo:.2f} x{halo1 / halo:.2f}", flush=True)
         del x, w, out
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rows, open("gpurun_out/halo_bench.json", "w"), indent=1)
