@@ -183,6 +183,10 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = col0 + j * 16;
+            // (a use of the loaded bias / residual on EVERY path: on the masked path below they would otherwise stay
+            // "pending" in the compiler's wait bookkeeping, and a kernel that calls this epilogue inside a loop - the
+            // persistent halo conv - then gets a compiler-inserted vmcnt(0) at the head of its MFMA loop)
+            asm volatile("" ::"v"(add[j]));
             if (!m_ok || n >= p.N) continue;
             float o[4];
             f32x4 cs = zero4;
