@@ -139,7 +139,7 @@ void lb_conv_halo_set_study(int bits);
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
-void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv, bit5 ENABLES the 192x128 rule (off by default) */
+void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv, bit5 ENABLES the general 192x128 rule (off by default), bit6 disables the narrow 192x128 rule (short K, single partial round) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached

@@ -1,5 +1,6 @@
 // 3x3 / stride 1 / pad 1 convolution - and the sub-pixel 2x2 form of the upsampler convs - from an LDS-resident HALO
-// tile (gfx950).  On the default route of lb_gemm_f16 since round 2 (lb_gemm_set_halo; 1.3-1.8x the implicit GEMM).
+// tile (gfx950).  On the default route of
+// lb_gemm_f16 since round 2 (lb_gemm_set_halo; measured 1.27-1.79x the implicit GEMM, up to 1.18 PFLOP/s).
 //
 // Why: the implicit-GEMM conv (gemm_glds.hip) stages every input pixel once per tap - 9 times - and the
 // ablation (profiles/r01_gemm_ablation.txt) shows the kernel family bound by exactly that global->LDS
@@ -15,24 +16,27 @@
 // Local pixel m = wave_m*64 + 16 i + l16  ->  (py, px) = (m / TW, m % TW): the 16 lanes of an MFMA row
 // group are 16 consecutive pixels of one image row (conflict-free LDS rows, contiguous NHWC stores).
 //
-// LDS (150 KiB): two halo buffers of HRP = 8*ceil((TH+2)(TW+2)/8) rows (running chunk cc in buffer cc & 1) and a
-// 4-slot ring of weight tiles (BN rows).  One STEP = one (chunk c, tap) pair: 32 MFMAs per wave, ONE s_barrier.
+// LDS (150 KiB): two halo buffers of HRP = 8*ceil((TH+2)(TW+2)/8) rows (chunk c in buffer c & 1) and a
+// 4-slot ring of weight tiles (BN rows).  One STEP = one (chunk c, tap) pair: 32 MFMAs per wave.
+//   * W(t) is requested 3 steps ahead (slot t & 3 was consumed by step t-4... t-1 before the barrier),
+//   * the halo of chunk c+1 is requested during taps 0..5 of chunk c (<= 1 load per thread and step),
+//   * per step every thread issues [halo load if any] then 2 weight loads, interleaved with the MFMAs.
+// Wait before step t (then ONE s_barrier): everything except the loads of steps t-1 and t-2 must have
+// landed => s_waitcnt vmcnt(cnt(tap-1) + cnt(tap-2)), cnt(tap) = 2 + [tap <= 4]; the 6th halo load exists
+// only in waves 0..(HRG-41) (tap 5) and is simply counted as absent: a wave that has it waits for one
+// more (older) load, never for fewer.  Past-the-end requests (last chunk's "next halo", the last three
+// steps' weight tiles) are still issued, masked to the zero page, so the constants hold to the end.
 //
-// Loader roles (round 2, after profiles/r02_halo_study.txt: with every wave issuing both streams the activation reads
-// cost 175-230 ns of a 900-1200 ns step and the epilogue 6 us per tile, neither overlapped - vmcnt retires in order, so
-// an HBM-latency halo request sat in front of the L2-latency weight requests every wave had to wait for 3 steps later,
-// and the first wait after an epilogue drained its stores):
-//   * waves 4..7 request the WEIGHT tiles: W(t) three steps ahead, 4 wave instructions per wave and step, and wait
-//     with vmcnt(8) (= their requests of steps t-1, t-2) before step t;
-//   * waves 0..3 request the HALO of the next chunk (11 rounds of 4 wave instructions during taps 0..5; 10 rounds during
-//     taps 0..1 for the 2x2 form) and wait - vmcnt(0) - only before tap 0 of the chunk that reads it: an activation
-//     request has up to 9 steps (~6 us) to land instead of 3.
-//   Each wave waits for its own requests, then the step's barrier publishes them to the others.
-// Persistent blocks (one per CU), request streams running across tile boundaries: see the kernel.  At a tile boundary
-// every wave drains its requests BEFORE the epilogue (they are 1-3 steps old), so the first three steps of the next
-// tile need no vmcnt wait at all (their operands have landed) and the epilogue's stores drain behind those steps.
-// Past-the-end weight requests (the last three steps of a block) are still issued, masked to the zero page, so the
-// weight waves' constant holds to the end; halo requests of a tile that does not exist are simply not issued.
+// Round 2: PERSISTENT blocks (one per CU walks items bid, bid + G, ...) whose request streams run across tile
+// boundaries (see the kernel).  profiles/r02_halo_study.txt splits a tile's time: MFMA + LDS alone run at 640-680 ns per
+// step (427 ns at the MFMA peak); activation reads add ~2 us per 64-channel chunk and the epilogue 4-6 us per tile.
+// Two follow-ups were built, verified bit-for-bit and measured, and are NOT in this file (git history has them):
+//   * separate loader roles (4 halo waves + 4 weight waves, so that an HBM-latency halo request never sits in front of the
+//     L2-latency weight requests in a wave's in-order vmcnt): +3-8 % on the VAE shapes in isolation, -5 % on the UNet's
+//     deep-K shapes, no gain inside the programs (profiles/r02_halo_variants.txt) - the per-chunk cost is not the wait
+//     order but the CU's request queue holding HBM-latency lines in front of the weight stream;
+//   * a full drain before each epilogue so that the next tile's first three steps run without a vmcnt wait while the
+//     stores retire: -1..-6 % on the VAE shapes in isolation, +3 % on the deep-K shapes, nothing inside the programs.
 #include <type_traits>
 #include "lb_common.h"
 #include "lb_gemm.h"
@@ -43,7 +47,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 template <int N> __device__ __forceinline__ void halo_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void halo_barrier_only() { asm volatile("s_barrier" ::: "memory"); }
 
 // KS = 3: the 3x3 / stride 1 / pad 1 convolution described above (9 taps per 64-channel chunk).
 // KS = 2: the SUB-PIXEL form of "nearest-2x upsample, then 3x3 conv" (LbGemmParams.scatter == 2): four 2x2 convolutions
@@ -51,7 +54,16 @@ __device__ __forceinline__ void halo_barrier_only() { asm volatile("s_barrier" :
 //   parities run in this one launch (the parity is part of the block index: 4x the blocks of one parity launch, one
 //   launch instead of four); a block's halo is (TH+1) x (TW+1) pixels starting at (y0 - (1-py), x0 - (1-px)), its
 //   4 taps per chunk read it through shifted rows, and its 256 x BN results are scattered to pixels (2y+py, 2x+px).
-constexpr unsigned HALO_NONE = 0xffffffffu;             // "no such pixel / row": request nothing (halo) or the zero page (weights)
+//   The next chunk's halo (5 rounds of wave instructions) is requested during taps 0 and 1 (3 + 2 rounds), because
+//   the wait before a step only guarantees everything older than the two previous steps.
+template <int KS, int J> struct HaloSched {             // tap during which round J of the NEXT chunk's halo is requested
+    static constexpr int tap = KS == 3 ? J : (J < 3 ? 0 : 1);
+};
+template <int KS, int NR, int TAP> constexpr int halo_full_rounds_in_tap() {   // rounds EVERY wave issues in step TAP
+    int n = 0;
+    for (int j = 0; j < NR - 1; ++j) n += ((KS == 3 ? j : (j < 3 ? 0 : 1)) == TAP) ? 1 : 0;   // (the last round is partial: counted as absent)
+    return n;
+}
 
 template <int BN, int TW, int KS = 3>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p) {
@@ -61,22 +73,20 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     constexpr int HR = (TH + KS - 1) * HWP;             // halo pixels (LDS rows in use)
     constexpr int HRG = (HR + 7) / 8;                   // 8-row groups = wave instructions per halo
     constexpr int HRP = HRG * 8;                        // rows per halo buffer
-    constexpr int NRH = (HRG + 3) / 4;                  // rounds of 4 wave instructions (one per halo wave; the last one partial)
-    constexpr int RPT = KS == 3 ? 2 : 5;                // halo rounds requested per tap (taps 0..5 / taps 0..1)
-    constexpr int WI = BN * 8 / 64 / 4;                 // weight wave instructions per weight wave and step (4)
+    constexpr int NR = (HRG + 7) / 8;                   // rounds of 8 wave instructions (the last one partial)
+    constexpr int EXTRA = HRG - 8 * (NR - 1);           // groups of the last, partial round (1..8)
+    constexpr int WI = BN * 8 / 512;                    // weight loads per thread and step (2)
     constexpr int TM = 4, TN = BN / 32;                 // 16x16 tiles per wave (64 pixels x BN/2 channels)
-    static_assert(NRH <= RPT * (KS == 3 ? 6 : 2), "halo rounds do not fit their taps");
-    static_assert(WI == 4, "the weight waves' vmcnt(8) assumes four requests per wave and step");
+    static_assert(NR == (KS == 3 ? 6 : 5), "halo rounds: 6 for the 3x3 form, 5 for the 2x2 form");
+    static_assert(EXTRA >= 1 && EXTRA <= 8, "the last halo round is a partial one");
+    static_assert(WI == 2, "the vmcnt schedule assumes two weight loads per thread and step");
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
     f16* const halo0 = lds;
     f16* const wring = lds + 2 * HRP * 64;              // 4 slots of BN rows
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int g = lane >> 4, l16 = lane & 15;
-    const bool halo_wave = wave < 4;
-    const int lw = wave & 3;                            // index among the waves of the same role
 
     // ---- work items: (pixel tile [, parity], channel block), channel block fastest; XCD-contiguous block ids ------
     // PERSISTENT form: the grid is G <= #CUs blocks (one per CU: the LDS footprint allows no more) and block `bid`
@@ -84,7 +94,9 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     // block keeps ONE weight slab (block_n, parity) for its whole life and only the pixel tile changes.  The request
     // streams do not stop at a tile boundary: during the last chunk of tile k the "next halo" is chunk 0 of tile k+1
     // and W(step + 3) wraps to its first taps, so the epilogue of tile k (global stores, no LDS) runs with the next
-    // tile's operands already resident.  With gridDim.x == number of items the same code is the one-item-per-block form.
+    // tile's operands already in flight - a block of the one-item-per-block form paid launch + first-halo latency +
+    // store drain (measured ~14 us, against 11 us of MFMA work for an 18-step Cin = 128 tile) once per tile.
+    // With gridDim.x == number of items the same code is the one-item-per-block form.
     const int n_blocks = (p.N + BN - 1) / BN;
     const int tiles_x = p.Win / TW, tiles_y = p.Hin / TH;
     const int n_items = (p.M / (p.Hin * p.Win)) * tiles_x * tiles_y * (KS == 2 ? 4 : 1) * n_blocks;
@@ -102,7 +114,6 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     const lb_half* Wp = p.W + (KS == 2 ? (long)(par_y * 2 + par_x) * p.N * p.ldw : 0);
     const int nchunks = p.Cin / 64;
     const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
-    const int study = p.reserved_;                      // timing studies only (lb_conv_halo_set_study): 1 no epilogue, 2 halo from the zero page, 4 weights from the zero page
 
     struct TileAt { int b, y0, x0; };
     auto tile_of = [&](int item) {                      // item -> image and tile origin (block-uniform: scalar registers)
@@ -116,46 +127,54 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         return t;
     };
 
-    // ---- loader state (offsets in 16-byte units: 32 bits reach 64 GiB) ------------------------------------------------
-    // a wave instruction moves 8 LDS rows x 128 B: lane (r8 = lane>>3, slot = lane&7) fetches logical chunk slot ^ r8 of row r8
+    // ---- loader state -------------------------------------------------------------------------------
+    // halo: wave instruction j (0..5) covers row group gidx(j); lane (r8 = lane>>3, slot = lane&7) fetches
+    // logical chunk slot ^ r8 of halo row gidx*8 + r8
     const int r8 = lane >> 3;
     const int cl = (lane & 7) ^ r8;
-    // halo wave: round j moves row group 4 j + lw.  The pixel address is recomputed at every request (a dozen VALU ops
-    // in the shadow of 32 MFMAs) instead of held in 11 registers per lane across the MFMA loop.
-    const int hrow0 = lw * 8 + r8;
-    unsigned w_off[WI];                                 // weight wave: rows (lw + 4 i) * 8 + r8 of the BN x 64 tile
+    long h_off[NR];                                     // element offset of the pixel (chunk 0) in the tile being REQUESTED, -1 = zero page
+    auto set_halo_offsets = [&](const TileAt& t, bool exists) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int gidx = j * 8 + wave;
+            const int row = gidx * 8 + r8;
+            const int hy = row / HWP, hx = row - hy * HWP;
+            const int y = t.y0 + hy - org_y, x = t.x0 + hx - org_x;
+            const bool ok = exists && (j < NR - 1 || wave < EXTRA) && row < HR && y >= 0 && y < p.Hin && x >= 0 && x < p.Win;
+            h_off[j] = ok ? ((long)(t.b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 : -1;
+        }
+    };
+    // weights: thread stages rows (tid>>3) + 64 i of the BN x 64 tile
+    long w_off[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int n = n0 + (lw + 4 * i) * 8 + r8;
-        w_off[i] = n < p.N ? (unsigned)(((long)n * p.ldw + cl * 8) >> 3) : HALO_NONE;
+        const int n = n0 + (tid >> 3) + i * 64;
+        w_off[i] = n < p.N ? (long)n * p.ldw + cl * 8 : -1;
     }
 
-    auto issue_halo = [&](int j, const TileAt& t, int src_chunk, int buf, bool tile_exists) {   // one wave instruction of a halo of tile t
-        const int gidx = j * 4 + lw;
-        if (gidx >= HRG || !tile_exists) return;        // (wave-uniform: no such row group in the partial last round / no such tile)
-        const int row = j * 32 + hrow0;
-        const int hy = row / HWP, hx = row - hy * HWP;
-        const int y = t.y0 + hy - org_y, x = t.x0 + hx - org_x;
-        // a row past the halo inside the last group, or a pixel outside the image: zero fill
-        const bool ok = y >= 0 && y < p.Hin && x >= 0 && x < p.Win && row < HR && !(study & 2);
-        const lb_half* src = ok ? p.A + ((long)(t.b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 + src_chunk * 64 : zero;
+    const int study = p.reserved_;                      // timing studies only (lb_conv_halo_set_study): 1 no epilogue, 2 halo from the zero page, 4 weights from the zero page
+    auto issue_halo = [&](int j, int src_chunk, int buf) {   // one wave instruction of a halo (of the tile h_off describes)
+        const lb_half* src = h_off[j] >= 0 && !(study & 2) ? p.A + h_off[j] + (long)src_chunk * 64 : zero;
+        const int gidx = j * 8 + wave;
         f16* dst = halo0 + buf * (HRP * 64) + gidx * 8 * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
     auto issue_weight = [&](int i, int chunk, bool exists, int tap, int slot) {
-        const bool live = w_off[i] != HALO_NONE && exists && !(study & 4);
-        const lb_half* src = live ? Wp + ((long)w_off[i] << 3) + (long)tap * p.Cin + (long)chunk * 64 : zero;
-        f16* dst = wring + slot * (BN * 64) + (lw + 4 * i) * 8 * 64;
+        const bool live = w_off[i] >= 0 && exists && !(study & 4);
+        const lb_half* src = live ? Wp + w_off[i] + (long)tap * p.Cin + (long)chunk * 64 : zero;
+        f16* dst = wring + slot * (BN * 64) + (wave * 8 + i * 64) * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
 
     // ---- consumer state -----------------------------------------------------------------------------
     int hbase[TM];                                      // halo row of tap (0, 0) of the lane's pixel i
+    int mloc[TM];                                       // the pixel's offset from the tile origin, in image pixels
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = wave_m * 64 + i * 16 + l16;
         const int py = m / TW, px = m - py * TW;
         hbase[i] = py * HWP + px;
+        mloc[i] = py * p.Win + px;
     }
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -184,33 +203,25 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     };
 
-    // ---- prologue: halo of chunk 0 of the first tile (halo waves), weight tiles of steps 0..2 (weight waves) ----------
+    // ---- prologue: halo of chunk 0 of the first tile, weight tiles of steps 0..2 ------------------------
     int item = bid;
     TileAt cur = tile_of(item);
-    if (halo_wave) {
+    set_halo_offsets(cur, true);
 #pragma unroll
-        for (int j = 0; j < NRH; ++j) issue_halo(j, cur, 0, 0, true);
-    } else {
+    for (int j = 0; j < NR; ++j)
+        if (j < NR - 1 || wave < EXTRA) issue_halo(j, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < WI; ++i) issue_weight(i, 0, true, t, t);
-    }
+        for (int i = 0; i < WI; ++i) issue_weight(i, 0, true, t, t);
 
-    // One step.  TAP and the loader ROLE (1 = halo wave) are compile-time constants: each role runs its own copy of
-    // the step code and all of them meet at the same barriers.  c = chunk within the tile, cc = chunks since the block
-    // started (halo buffer / weight slot parity run on across tiles), more = another tile follows, landed = the
-    // operands of this step were drained before the previous tile's epilogue (first three steps of a later tile).
-    auto step = [&](auto tap_c, auto role_c, int c, int cc, bool more, bool landed, const TileAt& hreq) {
+    // one step; TAP is a compile-time constant so that every count below is an immediate.  c = chunk within the tile,
+    // cc = chunks since the block started (halo buffer / weight slot parity run on across tiles), more = another tile follows
+    auto step = [&](auto tap_c, int c, int cc, bool more) {
         constexpr int TAP = decltype(tap_c)::value;
-        constexpr bool HALO = decltype(role_c)::value != 0;
-        if (landed && TAP < 3) {
-            halo_barrier_only();
-        } else if constexpr (HALO) {
-            if constexpr (TAP == 0) halo_wait_barrier<0>(); else halo_barrier_only();
-        } else {
-            halo_wait_barrier<2 * WI>();
-        }
+        constexpr int P1 = (TAP + NTAP - 1) % NTAP, P2 = (TAP + NTAP - 2) % NTAP;          // taps of the two previous steps
+        constexpr int CNT = (2 + halo_full_rounds_in_tap<KS, NR, P1>()) + (2 + halo_full_rounds_in_tap<KS, NR, P2>());
+        halo_wait_barrier<CNT>();
         const int slot = KS == 3 ? ((cc + TAP) & 3) : TAP;   // (NTAP cc + TAP) mod 4
         const f16* hb = halo0 + (cc & 1) * (HRP * 64);
         const f16* wb = wring + slot * (BN * 64);
@@ -219,11 +230,10 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         // loop-invariant, and hoisting them out of the chunk loop costs more registers than the file has
         int shift = KY * HWP + KX;
         asm volatile("" : "+v"(shift));
-        // requests of this step: rounds of the NEXT halo scheduled here (chunk c+1 of this tile, or chunk 0 of the next
-        // tile during the last chunk: hreq), or W(step + 3) (wrapping into the next tile likewise)
+        // requests of this step: rounds of the NEXT halo scheduled here (chunk c+1, or chunk 0 of the next tile: h_off
+        // was re-pointed at the start of the tile's last chunk), then W(step + 3) (wrapping into the next tile likewise)
         const bool last = c + 1 == nchunks;
         const int hc = last ? 0 : c + 1, hbuf = (cc + 1) & 1;
-        const bool h_exists = !last || more;
         constexpr int TAP3 = (TAP + 3) % NTAP;
         const bool wrap = (TAP + 3 >= NTAP) && last;
         const int c3 = wrap ? 0 : c + (TAP + 3) / NTAP;
@@ -231,84 +241,69 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         const int slot3 = (slot + 3) & 3;
         f16x8 a0[TM], w0[TN], a1[TM], w1[TN];
         read_frags(hb, wb, shift, 0, a0, w0);
-        if constexpr (HALO) {
-#pragma unroll
-            for (int r = 0; r < RPT; ++r)
-                if (TAP * RPT + r < NRH) issue_halo(TAP * RPT + r, hreq, hc, hbuf, h_exists);
-        }
+        if constexpr (HaloSched<KS, 0>::tap == TAP) issue_halo(0, hc, hbuf);
+        if constexpr (NR > 2 && HaloSched<KS, 1>::tap == TAP) issue_halo(1, hc, hbuf);
+        if constexpr (NR > 3 && HaloSched<KS, 2>::tap == TAP) issue_halo(2, hc, hbuf);
+        if constexpr (NR > 4 && HaloSched<KS, 3>::tap == TAP) { if (NR - 1 > 3 || wave < EXTRA) issue_halo(3, hc, hbuf); }
+        if constexpr (NR > 4 && HaloSched<KS, 4>::tap == TAP) { if (NR - 1 > 4 || wave < EXTRA) issue_halo(4, hc, hbuf); }
+        if constexpr (NR > 5 && HaloSched<KS, 5>::tap == TAP) { if (wave < EXTRA) issue_halo(5, hc, hbuf); }
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a0, w0, 0, TM / 2);
         read_frags(hb, wb, shift, 1, a1, w1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!HALO) { issue_weight(0, c3, w_exists, TAP3, slot3); issue_weight(1, c3, w_exists, TAP3, slot3); }
+        issue_weight(0, c3, w_exists, TAP3, slot3);
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a0, w0, TM / 2, TM);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!HALO) { issue_weight(2, c3, w_exists, TAP3, slot3); issue_weight(3, c3, w_exists, TAP3, slot3); }
+        issue_weight(1, c3, w_exists, TAP3, slot3);
         __builtin_amdgcn_sched_barrier(0);
         mma_rows(a1, w1, 0, TM);
     };
 
-    LbGemmParams q2;                                    // (KS == 2: this block's parity drives the scatter of the shared epilogue)
+    LbGemmParams q = p;                                 // (KS == 2: this block's parity drives the scatter of the shared epilogue)
     if constexpr (KS == 2) {
-        q2 = p;
-        q2.scatter = 1;
-        q2.sc_py = par_y;
-        q2.sc_px = par_x;
+        q.scatter = 1;
+        q.sc_py = par_y;
+        q.sc_px = par_x;
     }
-    const LbGemmParams& q = KS == 2 ? q2 : p;
 
-    // the tile loop of one role
-    auto run = [&](auto role_c) {
-        constexpr bool HALO = decltype(role_c)::value != 0;
-        int cc = 0;
-        bool first = true;
-        for (;;) {
-            const int next_item = item + G;
-            const bool more = next_item < n_items;
-            const TileAt nxt = tile_of(more ? next_item : item);
-            for (int c = 0; c < nchunks; ++c, ++cc) {
-                const TileAt hreq = c + 1 == nchunks ? nxt : cur;       // this tile's halos are all requested in its last chunk: aim at the next tile
-                const bool landed = c == 0 && !first;
-                step(std::integral_constant<int, 0>{}, role_c, c, cc, more, landed, hreq);
-                step(std::integral_constant<int, 1>{}, role_c, c, cc, more, landed, hreq);
-                step(std::integral_constant<int, 2>{}, role_c, c, cc, more, landed, hreq);
-                step(std::integral_constant<int, 3>{}, role_c, c, cc, more, landed, hreq);
-                if constexpr (KS == 3) {
-                    step(std::integral_constant<int, 4>{}, role_c, c, cc, more, landed, hreq);
-                    step(std::integral_constant<int, 5>{}, role_c, c, cc, more, landed, hreq);
-                    step(std::integral_constant<int, 6>{}, role_c, c, cc, more, landed, hreq);
-                    step(std::integral_constant<int, 7>{}, role_c, c, cc, more, landed, hreq);
-                    step(std::integral_constant<int, 8>{}, role_c, c, cc, more, landed, hreq);
-                }
+    int cc = 0;
+    for (;;) {
+        const int next_item = item + G;
+        const bool more = next_item < n_items;
+        const TileAt nxt = tile_of(more ? next_item : item);
+        for (int c = 0; c < nchunks; ++c, ++cc) {
+            if (c + 1 == nchunks) set_halo_offsets(nxt, more);      // this tile's halos are all requested: aim at the next tile
+            step(std::integral_constant<int, 0>{}, c, cc, more);
+            step(std::integral_constant<int, 1>{}, c, cc, more);
+            step(std::integral_constant<int, 2>{}, c, cc, more);
+            step(std::integral_constant<int, 3>{}, c, cc, more);
+            if constexpr (KS == 3) {
+                step(std::integral_constant<int, 4>{}, c, cc, more);
+                step(std::integral_constant<int, 5>{}, c, cc, more);
+                step(std::integral_constant<int, 6>{}, c, cc, more);
+                step(std::integral_constant<int, 7>{}, c, cc, more);
+                step(std::integral_constant<int, 8>{}, c, cc, more);
             }
-            // every request so far belongs to the next tile's first steps (or is a masked tail request): let it land now,
-            // so that those steps can run without a vmcnt wait while this epilogue's stores drain behind them
-            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0) (as the builtin: the compiler's own wait bookkeeping sees it)
-            const int mbase = (cur.b * p.Hin + cur.y0) * p.Win + cur.x0;    // (low-res pixel index; the epilogue scatters it for KS == 2)
-            // (the lane's first column goes through an opaque register: bias vectors, column masks and output offsets are
-            // tile-invariant, and the compiler would otherwise hoist them out of the tile loop and hold ~30 registers
-            // across the MFMA loop - which it then spills around this epilogue)
-            int col0 = n0 + wave_n * (BN / 2) + 4 * g;
-            asm volatile("" : "+v"(col0));
-            auto row_of = [&](int i) {                       // image pixel of the lane's i-th row: from the halo row of its tap (0, 0)
-                const int py = hbase[i] / HWP, px = hbase[i] - py * HWP;
-                return mbase + py * p.Win + px;
-            };
-            if (!(study & 1)) lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, row_of, col0, 0);
-            else if (acc[0][0][0] == 12345.678f) *(float*)p.C = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];   // (keeps the MFMAs alive)
-            if (!more) break;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            item = next_item;
-            cur = nxt;
-            first = false;
         }
-    };
-    if (halo_wave) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 0>{});
+        // epilogue of this tile (registers -> global memory; the next tile's first operands are in flight meanwhile)
+        const int mbase = (cur.b * p.Hin + cur.y0) * p.Win + cur.x0;    // (low-res pixel index; the epilogue scatters it for KS == 2)
+        // (the lane's first column goes through an opaque register: bias vectors, column masks and output offsets are
+        // tile-invariant, and the compiler would otherwise hoist them out of the tile loop and hold ~30 registers
+        // across the MFMA loop - which it then spills around this epilogue)
+        int col0 = n0 + wave_n * (BN / 2) + 4 * g;
+        asm volatile("" : "+v"(col0));
+        if (!(study & 1)) lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
+        else if (acc[0][0][0] == 12345.678f) *(float*)p.C = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];   // (keeps the MFMAs alive)
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        item = next_item;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the masked tail requests still target this block's LDS: drain before exit
 }
 
 // 1 (default): persistent blocks with the request streams running across tile boundaries; 0: one item per block

@@ -438,6 +438,12 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
                 const long cur = tile == 5 ? rounds5 * 174 : rounds4 * 100;
                 if (b192 >= 160 && rounds7 * 78 < cur) tile = 7;
             }
+            // ... except the one case where it did win in that measurement (24.9 vs 26.5 us): a short-K GEMM whose 256x128
+            // grid is a single partial round (the UNet's 192 M = 4352, N = 1280, K = 1280 projections per forward).
+            if (!(g_policy_off & 64) && !geglu && !p.conv && tile == 4 && n_fits && p.K <= 1536 && b256 < 224) {
+                const long b192 = blocks(192, 128);
+                if (b192 <= 256 && b192 * 10 >= b256 * 13) tile = 7;
+            }
         }
     }
     if (tile >= 4 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 6- / 8-wave tiles: direct-to-LDS family only

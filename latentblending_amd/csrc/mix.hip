@@ -149,10 +149,15 @@ __global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict_
 
 // Batch of pairs with element strides between consecutive pairs (0 = every pair reads the same tensor: the
 // parental mix of ONE pair of anchors at many fractions) and device-side fractions.  Each thread keeps its
+// (An fp32 shortcut for the weighted sum - r = fma32(a, w0f, b w1f), accepted when half(r - e) == half(r + e) for the
+// error bound e = 1.0625 * 2^-22 (|a w0f| + |b w1f|), else the float64 chain - is equal to the chain by construction and
+// was verified bit-for-bit on 42 M elements (tests, numpy emulation).  Measured SLOWER, 2.7 vs 3.55 TB/s
+// (profiles/r02_slerp_study.txt): ~0.2 % of the elements need the chain, i.e. one wave-iteration in eight, and the
+// compiler keeps both paths' operands live.  Not kept; the float64 chain below is the product path.)
 // VPT 16-byte vectors of both inputs in REGISTERS between the reduction and the weighted sum: HBM is read exactly
 // once (6 B / element) without an LDS round trip, the block needs 0.5 KiB of LDS, so four 512-thread blocks share a
 // CU and one block's loads overlap another's float64 arithmetic.
-// STUDY: 0 = product; 1 = lerp weights instead of the acos / sin chain; 2 = fp32 weighted sum (tools/slerp_study.py only)
+// STUDY: 0 = product; 1 = lerp weights instead of the acos / sin chain; 2 = fp32 weighted sum (NOT exact) (tools/slerp_study.py only)
 template <int VPT, int STUDY = 0>
 __global__ void __launch_bounds__(512) slerp_strided_kernel(const f16* __restrict__ p0, long stride0,
                                                              const f16* __restrict__ p1, long stride1,

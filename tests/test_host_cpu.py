@@ -470,7 +470,7 @@ def test_multi_transition_driver_and_movie_json(tmp_path, cpu_backend):
 def test_gemm_tile_policy_is_pinned():
     """lb_gemm_plan (pure host arithmetic of the launcher): the tile / split-K choices the MI355X sweeps led to
     (profiles/r01_gemm_*.txt, tools/ab_policy.py) for the shapes the SDXL programs launch.  Tiles: 1 = 128x128,
-    2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves)."""
+    2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves), 7 = 192x128 (6 waves)."""
     from latentblending_amd.hip import lib
 
     def plan(M, N, K, conv=False, geglu=False, ws=None, zero_page=True):
@@ -488,7 +488,7 @@ def test_gemm_tile_policy_is_pinned():
     # UNet at B=17 (M = 17*256 / 17*1024)
     assert plan(4352, 10240, 1280, geglu=True)[:2] == (5, 1)            # GEGLU: 256x256, 680 blocks
     assert plan(4352, 10240, 1280, geglu=True)[2] == 17 * 40
-    assert plan(4352, 1280, 1280)[:2] == (4, 1)                         # 170 blocks of 256x128
+    assert plan(4352, 1280, 1280) == (7, 1, 230)                        # short K, 170 blocks of 256x128 = 2/3 of the chip: 230 of 192x128
     assert plan(4352, 1280, 5120)[:2] == (4, 1)
     assert plan(4352, 2560, 1280)[:2] == (5, 1)                         # one round of 256x256 beats two of 256x128
     assert plan(17408, 640, 640)[0] in (1, 2)                           # short K: 4-wave tiles

@@ -1,5 +1,5 @@
 """Where does the batched slerp's time go?  Product kernel vs the same kernel with (1) lerp weights instead of the float64
-sqrt / acos / sin chain and (2) an fp32 weighted sum instead of the float64 one, on the >= 1 GiB batch."""
+sqrt / acos / sin chain and (2) an fp32 weighted sum instead of the float64 one (not exact), on the >= 1 GiB batch."""
 import os
 import sys
 
