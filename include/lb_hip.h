@@ -198,6 +198,11 @@ int lb_fill_f32(void* x, long n, float v, void* stream);
 int lb_embed_tokens_f16(const int* ids_dev, const void* tok_emb, const void* pos_emb, void* out, int rows, int seq, int C,
                         int vocab, void* stream);
 int lb_gather_rows_f16(const void* src, const int* rows_idx_dev, void* out, int n, int C, int ld_src, void* stream);
+/* Movie in-betweening (utils.py:166-176 add_frames_linear_interp -> :97 interpolate_linear on the uint8 key frames):
+ * frames = [n_key][frame_bytes] uint8 on the device, out[k] = uint8((1 - w[k]) * frames[left[k]] + w[k] * frames[left[k] + 1])
+ * in float64 as numpy >= 2 evaluates it, truncating cast.  frame_bytes % 16 == 0, n_out <= 65535. */
+int lb_frames_lerp_u8(const void* frames, const int* left_dev, const double* w_dev, void* out, long n_out,
+                      long frame_bytes, void* stream);
 int lb_copy_d2d(void* dst, const void* src, long bytes, void* stream);
 
 /* ---- launch programs (the MI355X-native stand-in for the reference's optional stable-fast

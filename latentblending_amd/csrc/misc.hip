@@ -298,3 +298,44 @@ extern "C" int lb_gather_rows_f16(const void* src, const int* rows_idx_dev, void
     LB_DISPATCH_STMT("lb_gather_rows_f16", hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * (C / 8))), dim3(256), 0, s,
                        (const f16*)src, rows_idx_dev, (f16*)out, n, C, ld_src));
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Frame in-betweening for the transition movie (reference utils.py:166-176 -> interpolate_linear :97 on float32 copies
+// of the uint8 key frames with a float64 weight): out[k] = uint8( (1 - w[k]) * frame[left[k]] + w[k] * frame[left[k]+1] ),
+// the products and the sum rounded to float64 as numpy evaluates them (NumPy >= 2 promotes the float32 array with the
+// float64 scalar to float64), the cast truncating.  16 bytes per thread.
+// ------------------------------------------------------------------------------------------
+typedef unsigned char u8x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) frames_lerp_u8_kernel(const unsigned char* __restrict__ frames, const int* __restrict__ left,
+                                                             const double* __restrict__ w, unsigned char* __restrict__ out,
+                                                             long frame_bytes) {
+    const long k = blockIdx.y;
+    const unsigned char* a = frames + (long)left[k] * frame_bytes;
+    const unsigned char* b = a + frame_bytes;
+    unsigned char* o = out + k * frame_bytes;
+    const double wk = w[k], w0 = 1.0 - wk;
+    const long nvec = frame_bytes >> 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const u8x16 va = *reinterpret_cast<const u8x16*>(a + i * 16), vb = *reinterpret_cast<const u8x16*>(b + i * 16);
+        u8x16 r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            r[e] = (unsigned char)(int)__dadd_rn(__dmul_rn(w0, (double)va[e]), __dmul_rn(wk, (double)vb[e]));
+        *reinterpret_cast<u8x16*>(o + i * 16) = r;
+    }
+    for (long i = (nvec << 4) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < frame_bytes; i += (long)gridDim.x * blockDim.x)
+        o[i] = (unsigned char)(int)__dadd_rn(__dmul_rn(w0, (double)a[i]), __dmul_rn(wk, (double)b[i]));
+}
+
+extern "C" int lb_frames_lerp_u8(const void* frames, const int* left_dev, const double* w_dev, void* out, long n_out,
+                                 long frame_bytes, void* stream) {
+    LB_REQUIRE(n_out > 0 && n_out <= 65535 && frame_bytes > 0, "lb_frames_lerp_u8: 1..65535 output frames");
+    LB_REQUIRE(((uintptr_t)frames & 15) == 0 && ((uintptr_t)out & 15) == 0 && frame_bytes % 16 == 0,
+               "lb_frames_lerp_u8: 16-byte aligned buffers, frame size a multiple of 16 bytes");
+    long bx = (frame_bytes / 16 + 255) / 256;
+    if (bx > 512) bx = 512;
+    LB_DISPATCH_STMT("lb_frames_lerp_u8", hipLaunchKernelGGL(frames_lerp_u8_kernel, dim3((unsigned)bx, (unsigned)n_out), dim3(256), 0, s,
+                       (const unsigned char*)frames, left_dev, w_dev, (unsigned char*)out, frame_bytes));
+}

@@ -96,6 +96,7 @@ SIGNATURES = {
     "lb_lpips_tap": (_i, [c_void_pp, c_void_pp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "lb_fill_f32": (_i, [_vp, _l, _f, _vp]),
     "lb_embed_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "lb_frames_lerp_u8": (_i, [_vp, _vp, _vp, _vp, _l, _l, _vp]),
     "lb_gather_rows_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "lb_copy_d2d": (_i, [_vp, _vp, _l, _vp]),
     "lb_program_create": (_vp, []),

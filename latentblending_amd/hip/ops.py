@@ -324,3 +324,19 @@ def maxpool3s2(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty(N, (H - 3) // 2 + 1, (W - 3) // 2 + 1, Cc, dtype=F16, device=x.device)
     api.lb_maxpool3s2_nhwc_f16(x.data_ptr(), y.data_ptr(), N, H, W, Cc, stream_ptr())
     return y
+
+
+def frames_lerp_u8(frames: torch.Tensor, left, weights) -> torch.Tensor:
+    """frames: [n_key, H, W, 3] uint8 on the device; out[k] = uint8((1 - w[k]) * frames[left[k]] + w[k] * frames[left[k] + 1])
+    in float64 with a truncating cast (reference utils.py:97 as numpy >= 2 evaluates it on the movie's key frames)."""
+    assert frames.dtype == torch.uint8 and frames.is_contiguous()
+    n_out = len(left)
+    fb = frames[0].numel()
+    left_d = torch.tensor(list(left), dtype=torch.int32, device=frames.device)
+    w_d = torch.tensor(list(weights), dtype=F64, device=frames.device)
+    out = torch.empty((n_out,) + tuple(frames.shape[1:]), dtype=torch.uint8, device=frames.device)
+    for k0 in range(0, n_out, 65535):
+        k1 = min(n_out, k0 + 65535)
+        api.lb_frames_lerp_u8(frames.data_ptr(), left_d[k0:].data_ptr(), w_d[k0:].data_ptr(), out[k0:].data_ptr(), k1 - k0, fb,
+                              stream_ptr())
+    return out

@@ -54,6 +54,17 @@ def interpolate_linear(p0, p1, fract_mixing):
     return out
 
 
+def _device_frame_stack(list_imgs):
+    """[n, H, W, 3] uint8 device tensor when every frame is a device-resident ``DeviceImage`` of one size whose byte
+    count the kernel accepts (multiple of 16), else None (host path)."""
+    frames = [getattr(im, "_lb_u8", None) for im in list_imgs]
+    if not frames or any(f is None or not f.is_cuda or f.shape != frames[0].shape for f in frames):
+        return None
+    if frames[0].numel() % 16 != 0:
+        return None
+    return torch.stack([f.contiguous() for f in frames])
+
+
 def add_frames_linear_interp(list_imgs: List[np.ndarray],
                              fps_target: Optional[Number] = None,
                              duration_target: Optional[Number] = None,
@@ -75,7 +86,6 @@ def add_frames_linear_interp(list_imgs: List[np.ndarray],
     if n_missing < 1:
         return list_imgs
 
-    frames = [np.asarray(im).astype(np.float32) for im in list_imgs]
     mean_insert = n_missing / n_gaps
     base = np.floor(mean_insert)
     threshold = 1 - (mean_insert - base)
@@ -91,6 +101,18 @@ def add_frames_linear_interp(list_imgs: List[np.ndarray],
             break
     per_gap = per_gap.astype(np.int32)
 
+    dev = _device_frame_stack(list_imgs)
+    if dev is not None:                 # key frames resident in HBM (native pipe): blend them there, one copy back
+        from .hip import ops
+        left, weights = [], []
+        for g in range(n_gaps):
+            for w in np.linspace(0, 1, per_gap[g] + 2)[:-1]:        # w = 0 reproduces the key frame itself
+                left.append(g)
+                weights.append(float(w))
+        blended = ops.frames_lerp_u8(dev, left, weights).cpu().numpy()
+        return [blended[k] for k in range(blended.shape[0])] + [dev[-1].cpu().numpy()]
+
+    frames = [np.asarray(im).astype(np.float32) for im in list_imgs]
     out: List[np.ndarray] = []
     for g in range(n_gaps):
         left, right = frames[g], frames[g + 1]

@@ -12,6 +12,11 @@ Fixtures
   scheduler.json  closed-form SDXL sigma / timestep known answers
   tree.json       a full run_transition of the reference BlendingEngine on the tiny CPU oracle pipe:
                   census, tree_fracts, tree_idx_injection, similarities, latent / frame checksums
+  frames.json     add_frames_linear_interp of the reference (utils.py:105-178) on seeded uint8 key frames with a seeded
+                  numpy RNG: per-gap insert counts and a checksum of every output frame (numpy 2.x arithmetic: the
+                  float32 frames are blended in float64)
+
+    python -m oracle.make_golden frames      # regenerate one fixture
 """
 from __future__ import annotations
 
@@ -214,14 +219,37 @@ def tree_fixture(ref):
     return runs
 
 
+def key_frames(seed, n, h, w):
+    rng = np.random.RandomState(seed)
+    return [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(n)]
+
+
+def frames_fixture(ref):
+    """reference utils.add_frames_linear_interp, executed unchanged."""
+    cases = []
+    for seed, n, h, w, target, rng_seed in [(11, 4, 16, 16, 23, 5), (12, 3, 8, 32, 9, 6), (13, 5, 16, 16, 64, 7), (14, 2, 16, 16, 2, 8)]:
+        imgs = key_frames(seed, n, h, w)
+        np.random.seed(rng_seed)
+        out = ref.utils.add_frames_linear_interp([i.copy() for i in imgs], nmb_frames_target=target)
+        cases.append({"seed": seed, "n": n, "h": h, "w": w, "target": target, "rng_seed": rng_seed,
+                      "numpy": np.__version__, "count": len(out), "sha": [sha(np.asarray(o)) for o in out],
+                      "head": [[int(v) for v in np.asarray(o).flatten()[:8]] for o in out]})
+    return cases
+
+
 def main():
+    import sys
     os.makedirs(OUT, exist_ok=True)
     ref = H.load_reference()
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    for name, data in [("planner", planner_fixture(ref)), ("slerp", slerp_fixture(ref)), ("scheduler", scheduler_fixture()),
-                       ("tree", tree_fixture(ref))]:
+    only = set(sys.argv[1:])
+    makers = [("planner", lambda: planner_fixture(ref)), ("slerp", lambda: slerp_fixture(ref)), ("scheduler", scheduler_fixture),
+              ("tree", lambda: tree_fixture(ref)), ("frames", lambda: frames_fixture(ref))]
+    for name, make in makers:
+        if only and name not in only:
+            continue
         with open(os.path.join(OUT, name + ".json"), "w") as fh:
-            json.dump(data, fh, indent=1)
+            json.dump(make(), fh, indent=1)
         print("wrote", name)
 
 

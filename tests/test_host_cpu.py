@@ -379,6 +379,28 @@ def test_host_utilities_and_movie_writer(tmp_path):
     assert blob[:4] == b"RIFF" and blob[8:12] == b"AVI " and blob.count(b"00dc") >= 10
 
 
+def golden_key_frames(seed, n, h, w):
+    rng = np.random.RandomState(seed)
+    return [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(n)]
+
+
+def frame_sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a)).tobytes()).hexdigest()[:16]
+
+
+def test_frame_inbetweening_matches_reference_golden():
+    """add_frames_linear_interp (host path) against tests/golden/frames.json = the unchanged reference's
+    utils.add_frames_linear_interp on the same seeded key frames and numpy RNG (oracle/make_golden.py frames_fixture)."""
+    from latentblending_amd import utils
+    for c in json.load(open(os.path.join(GOLD, "frames.json"))):
+        imgs = golden_key_frames(c["seed"], c["n"], c["h"], c["w"])
+        np.random.seed(c["rng_seed"])
+        out = utils.add_frames_linear_interp(imgs, nmb_frames_target=c["target"])
+        assert len(out) == c["count"]
+        assert [frame_sha(o) for o in out] == c["sha"]
+
+
 def test_movie_concatenation_and_lunar_tools_facade(tmp_path):
     """lunar_tools.concatenate_movies stand-in (example_multi_trans.py:62): parts back to back, payloads kept."""
     import lunar_tools

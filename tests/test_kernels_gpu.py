@@ -136,6 +136,35 @@ def test_slerp_strided(n, results_log):
     assert u <= 1 and ub <= 1
 
 
+def test_frame_inbetweening_on_device_matches_reference_golden(results_log):
+    """lb_frames_lerp_u8 through add_frames_linear_interp on DeviceImage key frames: every output frame equals the
+    unchanged reference's (tests/golden/frames.json), byte for byte; plus a 512x512 case against the host path."""
+    import hashlib
+    import json
+    import numpy as np
+    from latentblending_amd import utils
+    from latentblending_amd.native.frames import DeviceImage
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(np.asarray(a)).tobytes()).hexdigest()[:16]
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frames.json")))
+    for c in gold:
+        rng = np.random.RandomState(c["seed"])
+        imgs = [rng.randint(0, 256, size=(c["h"], c["w"], 3)).astype(np.uint8) for _ in range(c["n"])]
+        dev = [DeviceImage(torch.from_numpy(i).to(DEV)) for i in imgs]
+        assert utils._device_frame_stack(dev) is not None or c["target"] <= c["n"]
+        np.random.seed(c["rng_seed"])
+        out = utils.add_frames_linear_interp(dev, nmb_frames_target=c["target"])
+        assert len(out) == c["count"]
+        assert [sha(o) for o in out] == c["sha"], f"case seed {c['seed']}"
+    rng = np.random.RandomState(3)
+    imgs = [rng.randint(0, 256, size=(512, 512, 3)).astype(np.uint8) for _ in range(5)]
+    np.random.seed(9)
+    host = utils.add_frames_linear_interp(imgs, nmb_frames_target=40)
+    np.random.seed(9)
+    devo = utils.add_frames_linear_interp([DeviceImage(torch.from_numpy(i).to(DEV)) for i in imgs], nmb_frames_target=40)
+    assert len(host) == len(devo) == 40 and all(np.array_equal(a, b) for a, b in zip(host, devo))
+    results_log["frames_lerp_u8"] = {"golden_cases": len(gold), "full_size_frames": 40}
+
+
 def test_lerp_bit_exact(results_log):
     o = ops()
     a, b = rnd(1, 77, 2048, seed=11), rnd(1, 77, 2048, seed=12)
