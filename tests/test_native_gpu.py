@@ -183,6 +183,44 @@ def test_transition_tree_matches_oracle(turbo, results_log):
     assert same_tree, (be_o.tree_fracts, be_p.tree_fracts)
 
 
+def test_chained_transitions_match_oracle(results_log):
+    """The multi-transition flow of the reference's example_multi_trans.py:39-58 - run_transition, swap_forward,
+    new prompt2, run_transition(recycle_img1=True) - native engine (HIP) vs the same engine on the CPU oracle pipe:
+    same trees in both transitions, the recycled anchor is the previous transition's last frame, frames close."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    o, p, tape = make_pair(turbo=True)
+    engines = {}
+    for name, pipe_, backend in (("oracle", o, R.TorchCpuBackend()), ("native", p, None)):
+        set_backend(backend)
+        np.random.seed(0)
+        be = BlendingEngine(pipe_, metric=R.OracleLPIPS(7), verbose=False) if name == "oracle" else BlendingEngine(pipe_, verbose=False)
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=5)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        (o.noise if name == "oracle" else tape).reset()
+        first = be.run_transition(fixed_seeds=[420, 421])
+        t1 = (list(be.tree_fracts), list(be.tree_idx_injection))
+        be.swap_forward()
+        be.set_prompt2("a forest in the fog")
+        second = be.run_transition(recycle_img1=True, fixed_seeds=[421, 999])
+        engines[name] = {"first": [np.asarray(i).astype(np.int32) for i in first], "second": [np.asarray(i).astype(np.int32) for i in second],
+                         "t1": t1, "t2": (list(be.tree_fracts), list(be.tree_idx_injection)),
+                         "last2": be.tree_latents[-1][-1].float().cpu()}
+    set_backend(None)
+    a, b = engines["native"], engines["oracle"]
+    assert a["t1"] == b["t1"] and a["t2"] == b["t2"], (a["t1"], b["t1"], a["t2"], b["t2"])
+    d1 = np.stack([np.abs(x - y) for x, y in zip(a["first"], b["first"])])
+    d2 = np.stack([np.abs(x - y) for x, y in zip(a["second"], b["second"])])
+    # the second transition starts from the first one's last frame
+    assert np.array_equal(a["second"][0], a["first"][-1])
+    err = rel_l2(a["last2"], b["last2"])
+    results_log["chained_transitions"] = {"frames": [len(a["first"]), len(a["second"])], "mean_abs_u8": [float(d1.mean()), float(d2.mean())],
+                                          "final_latent_rel_l2": err, "same_trees": True}
+    assert d1.mean() <= 2 and d2.mean() <= 2 and err <= 3e-2
+
+
 def test_frontier_equals_sequential(results_log):
     """Speculative batched frontier commits exactly the sequential greedy tree (same native pipe)."""
     from latentblending_amd import BlendingEngine
