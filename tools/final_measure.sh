@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-end measurement on one MI355X (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats of the driver's bench command            -> gpurun_out/<tag>_stats/
+#   2. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, eager)   -> gpurun_out/<tag>_pmc_*/
+#   3. tools/pmc_summary.py folds them into profiles/<tag>_rocprof_summary.json  (bench.py reads roofline.traffic from it)
+#   4. the bench line itself, cfg 2 (+ the secondary lines: skewed metric, cfg 3)
+# Raw traces are dropped after summarising (gpurun merges at most 64 MiB back).
+TAG=${1:-r02}
+R=$PWD
+OUT=$R/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 20 --warmup 5"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $R/bench.py $ARGS --no-cpu-baseline --no-roofline > $OUT/${TAG}_stats.log 2>&1
+echo "stats rc=$?"
+PARGS="--steps 4 --warmup 1"
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python $R/bench.py $PARGS --no-graphs --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_$C.log 2>&1
+  echo "pmc $C rc=$?"
+done
+cd $R
+python tools/pmc_summary.py $TAG gpurun_out "$ARGS (kernel stats) / $PARGS (PMC passes)" > $OUT/${TAG}_pmc_summary.log 2>&1
+cp profiles/${TAG}_rocprof_summary.json $OUT/ 2>/dev/null
+# keep the per-kernel summaries, drop the raw traces
+for f in $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" -o -name "*domain_stats.csv"); do cp $f $OUT/${TAG}_bench_$(basename $f | sed 's/^[0-9]*_//'); done
+find $OUT/${TAG}_stats $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -type f -size +2M -delete 2>/dev/null
+timeout 400 python bench.py $ARGS > $OUT/${TAG}_bench_1gpu.json 2> $OUT/${TAG}_bench_1gpu.err
+echo "bench rc=$?"; tail -c 600 $OUT/${TAG}_bench_1gpu.json | head -c 600; echo
+timeout 300 python bench.py --steps 6 --warmup 2 --metric-skew 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_skew3.json 2> $OUT/${TAG}_bench_skew3.err
+echo "skew rc=$?"
+timeout 400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_cfg3.json 2> $OUT/${TAG}_bench_cfg3.err
+echo "cfg3 rc=$?"
+ls -la $OUT | head -40
+du -sh $OUT

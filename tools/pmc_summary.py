@@ -7,22 +7,24 @@ import glob
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"      # directory holding <tag>_stats/, <tag>_pmc_FETCH_SIZE/, <tag>_pmc_WRITE_SIZE/
+bench_args = sys.argv[3] if len(sys.argv) > 3 else "--steps 20 --warmup 5"
 
 
 def family(name):
-    if "gemm_f16" in name:
+    if "gemm_f16" in name or "conv3x3_halo" in name:
         return "gemm"
     if "splitk_reduce" in name:
         return "gemm_splitk_reduce"
-    for k in ("attn_fwd", "layernorm", "gn_apply", "gn_partial", "cast_f32", "slerp", "lerp", "euler", "lpips", "softmax"):
+    for k in ("attn_fwd", "layernorm", "gn_apply", "gn_partial", "cast_f32", "slerp", "lerp", "euler", "lpips", "softmax", "scale_input"):
         if k in name:
             return k
     return "other"
 
 
 out = {}
-stats = glob.glob("gpurun_out/rocprof_final/**/*kernel_stats.csv", recursive=True) or glob.glob("gpurun_out/rocprof_final/*kernel_stats.csv")
+stats = glob.glob(f"{src}/{tag}_stats/**/*kernel_stats.csv", recursive=True) or glob.glob(f"{src}/{tag}_stats/*kernel_stats.csv")
 if stats:
     fam = collections.defaultdict(lambda: [0.0, 0])
     with open(stats[0]) as fh:
@@ -33,9 +35,10 @@ if stats:
     total = sum(v[0] for v in fam.values())
     out["kernel_time_by_family"] = {k: {"total_ms": v[0] / 1e6, "calls": v[1], "avg_us": v[0] / v[1] / 1e3,
                                         "share": v[0] / total} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
+    out["kernel_stats_command"] = f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py {bench_args} --no-cpu-baseline --no-roofline"
 pmc = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob(f"gpurun_out/pmc_{counter}/**/*counter_collection.csv", recursive=True)
+    files = glob.glob(f"{src}/{tag}_pmc_{counter}/**/*counter_collection.csv", recursive=True)
     if not files:
         continue
     tot, n = 0.0, 0
@@ -52,7 +55,8 @@ if len(pmc) == 2:
     out["gemm_family_hbm_traffic"] = {"launches": n, "fetch_bytes_corrected": fetch, "write_bytes": write,
                                       "bytes_per_launch": (fetch + write) / n,
                                       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                                              "`bench.py --steps 1 --warmup 1 --no-graphs`; FETCH x2 correction "
-                                              "(MI355X_MICROARCH.md §HBM); Infinity-Cache hits are counted"}
+                                              f"`bench.py {bench_args} --no-graphs --no-cpu-baseline --no-roofline`; FETCH x2 correction "
+                                              "(MI355X_MICROARCH.md §HBM); Infinity-Cache hits are counted; GEMM family = "
+                                              "gemm_f16_* + conv3x3_halo_kernel launches"}
 json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
