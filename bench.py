@@ -341,9 +341,16 @@ def _run():
     base = args.config == "cfg3"
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not base
     t0 = time.perf_counter()
-    unet_prov, vae_prov = N.SyntheticProvider(0, keep=want_cpu), N.SyntheticProvider(1, keep=want_cpu)
+    # LB_SYNTH_CACHE=<dir>: keep the generated (seeded, fp16-rounded) tensors in a scratch file between the several
+    # processes of a profiling session - the same values, a few seconds instead of a minute of CPU random draws
+    cdir = os.environ.get("LB_SYNTH_CACHE")
+    cfile = (lambda s: os.path.join(cdir, f"lb_synth_seed{s}.pt")) if cdir else (lambda s: None)
+    unet_prov = N.SyntheticProvider(0, keep=want_cpu, cache_file=cfile(0))
+    vae_prov = N.SyntheticProvider(1, keep=want_cpu, cache_file=cfile(1))
     pipe = N.NativeSDXLPipe(turbo=not base, unet_provider=unet_prov, vae_provider=vae_prov, device=f"cuda:{local_rank}",
                             allow_synthetic=True)      # ("data": "synthetic" in the JSON line)
+    if rank == 0:
+        unet_prov.save_cache(); vae_prov.save_cache()
     t_weights = time.perf_counter() - t0
     unet_w, vae_w = unet_prov.state, vae_prov.state
     farm = None

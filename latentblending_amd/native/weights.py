@@ -29,29 +29,51 @@ def _seeded(name: str, shape: Sequence[int], std: float, seed: int, mean: float 
 
 
 class SyntheticProvider:
-    def __init__(self, seed: int = 0, keep: bool = False):
+    def __init__(self, seed: int = 0, keep: bool = False, cache_file: Optional[str] = None):
         """``keep``: remember every generated tensor in ``self.state`` (HF key -> fp32 tensor), e.g.
-        so that a benchmark can time a CPU checker on exactly the weights the device path uses."""
+        so that a benchmark can time a CPU checker on exactly the weights the device path uses.
+        ``cache_file``: a scratch file holding the generated tensors (fp16, exact: every value is rounded to fp16
+        anyway).  Drawing 2.6 G normal deviates from one CPU generator takes about a minute per process; profiling
+        sessions that start the same benchmark several times load the file instead (``save_cache`` writes it)."""
         self.seed = seed
         self.state: Optional[Dict[str, torch.Tensor]] = {} if keep else None
+        self.cache_file = cache_file
+        self._cache: Optional[Dict[str, torch.Tensor]] = None
+        self._fresh: Dict[str, torch.Tensor] = {}
+        if cache_file and os.path.isfile(cache_file):
+            self._cache = torch.load(cache_file, map_location="cpu", mmap=True, weights_only=True)
 
-    def _out(self, name: str, t: torch.Tensor) -> torch.Tensor:
-        t = t.half().float()
+    def save_cache(self) -> None:
+        if self.cache_file and self._cache is None and self._fresh:
+            tmp = self.cache_file + f".tmp{os.getpid()}"
+            torch.save(self._fresh, tmp)
+            os.replace(tmp, self.cache_file)
+        self._fresh = {}
+
+    def _out(self, name: str, shape: Sequence[int], make) -> torch.Tensor:
+        shape = tuple(shape)
+        if self._cache is not None and name in self._cache and tuple(self._cache[name].shape) == shape:
+            t = self._cache[name].float()
+        else:
+            h = make().half()
+            if self.cache_file and self._cache is None:
+                self._fresh[name] = h
+            t = h.float()
         if self.state is not None:
             self.state[name] = t
         return t
 
     def weight(self, name: str, shape: Sequence[int], fan_in: int, gain: float = 1.0) -> torch.Tensor:
-        return self._out(name, _seeded(name, shape, gain / math.sqrt(fan_in), self.seed))
+        return self._out(name, shape, lambda: _seeded(name, shape, gain / math.sqrt(fan_in), self.seed))
 
     def bias(self, name: str, n: int) -> torch.Tensor:
-        return self._out(name, _seeded(name, (n,), 0.02, self.seed))
+        return self._out(name, (n,), lambda: _seeded(name, (n,), 0.02, self.seed))
 
     def norm_weight(self, name: str, n: int) -> torch.Tensor:
-        return self._out(name, _seeded(name, (n,), 0.05, self.seed, mean=1.0))
+        return self._out(name, (n,), lambda: _seeded(name, (n,), 0.05, self.seed, mean=1.0))
 
     def positive(self, name: str, n: int) -> torch.Tensor:        # LPIPS lin layers (non-negative)
-        return self._out(name, _seeded(name, (n,), 1.0, self.seed).abs() / n)
+        return self._out(name, (n,), lambda: _seeded(name, (n,), 1.0, self.seed).abs() / n)
 
 
 class DictProvider:

@@ -10,6 +10,7 @@ R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export LB_SYNTH_CACHE=/tmp          # seeded synthetic weights: generated once, the later processes load them
 ARGS="--steps 20 --warmup 5"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $R/bench.py $ARGS --no-cpu-baseline --no-roofline > $OUT/${TAG}_stats.log 2>&1
 echo "stats rc=$?"
