@@ -150,6 +150,7 @@ class StableDiffusionXLPipeline:
         self._unet_programs: "OrderedDict[Tuple[int, int], UNetProgram]" = OrderedDict()
         self._vae_programs: "OrderedDict[Tuple[int, int], VAEProgram]" = OrderedDict()
         self.max_cached_programs = 8
+        self._embed_cache: OrderedDict = OrderedDict()           # text -> (prompt_embeds, pooled); cleared when the encoder changes
         self._use_graphs = False
         self._feat_scratch: Dict[int, list] = {}
         self.stats = {"unet_forwards": 0, "unet_samples": 0, "vae_decodes": 0, "slerps": 0, "lpips_pairs": 0}
@@ -182,11 +183,27 @@ class StableDiffusionXLPipeline:
     def prepare_extra_step_kwargs(self, generator, eta):
         return {"generator": generator}
 
+    @property
+    def text_encoder_fn(self):
+        return self._text_encoder_fn
+
+    @text_encoder_fn.setter
+    def text_encoder_fn(self, fn):
+        self._text_encoder_fn = fn
+        cache = getattr(self, "_embed_cache", None)
+        if cache is not None:
+            cache.clear()                                 # embeddings of another encoder are not this one's
+
     def encode_prompt(self, prompt=None, prompt_2=None, device=None, num_images_per_prompt=1,
                       do_classifier_free_guidance=True, negative_prompt=None, negative_prompt_2=None, **_):
         c = self.unet_cfg
 
         def embed(text):
+            # embedding cache keyed by the text: chained transitions re-encode the prompt they share
+            hit = self._embed_cache.get(text)
+            if hit is not None:
+                self._embed_cache.move_to_end(text)
+                return hit[0].clone(), hit[1].clone()
             if self.text_encoder_fn is not None:
                 pe, pooled = self.text_encoder_fn(text)
             else:
@@ -194,7 +211,11 @@ class StableDiffusionXLPipeline:
                                        "pass text_encoder_fn=native.clip.NativeTextEncoders(...).encode")
                 pe = _synthetic_embedding(text, (1, 77, c.cross_dim), 1)
                 pooled = _synthetic_embedding(text, (1, c.pooled_dim), 2)
-            return pe.to(self.device, F16), pooled.to(self.device, F16)
+            pe, pooled = pe.to(self.device, F16), pooled.to(self.device, F16)
+            self._embed_cache[text] = (pe.clone(), pooled.clone())
+            while len(self._embed_cache) > 64:
+                self._embed_cache.popitem(last=False)
+            return pe, pooled
 
         text = prompt if isinstance(prompt, str) else prompt[0]
         pe, pooled = embed(text)

@@ -497,14 +497,23 @@ def test_prompt_conditioning_through_the_pipe(results_log):
     enc = n.NativeTextEncoders(n.NativeCLIPText(c1, n.SyntheticProvider(3), DEV), n.NativeCLIPText(c2, n.SyntheticProvider(4), DEV),
                                allow_synthetic=True)
     ucfg, vcfg = R.tiny_unet_cfg(), R.tiny_vae_cfg()            # cross_dim 256 = 128 + 128, pooled_dim 128
+    calls = []
+
+    def counted_encode(text):
+        calls.append(text)
+        return enc.encode(text)
     pipe = n.NativeSDXLPipe(turbo=True, unet_cfg=n.UNetConfig(**dataclasses.asdict(ucfg)),
-                            vae_cfg=n.VAEConfig(**dataclasses.asdict(vcfg)), text_encoder_fn=enc.encode)
+                            vae_cfg=n.VAEConfig(**dataclasses.asdict(vcfg)), text_encoder_fn=counted_encode)
     pe, npe, pooled, npooled = pipe.encode_prompt("photo of a reef", do_classifier_free_guidance=True, negative_prompt="blurry")
     assert pe.shape == (1, 77, 256) and pooled.shape == (1, 128) and pe.dtype == torch.float16
     assert npe.shape == pe.shape and not torch.equal(npe, pe)
     pe2 = pipe.encode_prompt("rendering of an alien planet", do_classifier_free_guidance=False)[0]
     assert not torch.equal(pe, pe2)
     assert torch.equal(pe, pipe.encode_prompt("photo of a reef", do_classifier_free_guidance=False)[0])   # deterministic
+    assert calls == ["photo of a reef", "blurry", "rendering of an alien planet"]     # ... and served from the embedding cache
+    pe.zero_()                                                                        # callers own what they get back
+    again = pipe.encode_prompt("photo of a reef", do_classifier_free_guidance=False)[0]
+    assert len(calls) == 3 and float(again.abs().sum()) > 0 and not torch.equal(again, pe)
     be = BlendingEngine(pipe, verbose=False, frontier_width=4)
     be.set_dimensions((128, 128))
     be.set_branching(nmb_max_branches=3)
