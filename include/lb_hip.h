@@ -132,6 +132,9 @@ int lb_conv3x3_halo_f16(const LbGemmParams* params, void* stream);
 /* Tuning: 1 (default) = persistent blocks (one per CU) whose operand request streams run across tile boundaries;
  * 0 = one (tile, channel block) item per block. */
 void lb_conv_halo_set_persistent(int on);
+/* Host arithmetic of a halo launch (no device work): kind 0 = not eligible, 3 = 3x3 form, 2 = 2x2 sub-pixel form; the
+ * tile width (32 / 16), the number of (tile [, parity], channel block) work items and the grid that walks them. */
+void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long* items, long* grid);
 /* Timing studies only (tools/halo_study.py): bit 0 skip the epilogue, bit 1 / bit 2 halo / weight requests from the zero
  * page.  Any non-zero value makes the results wrong by construction; default 0. */
 void lb_conv_halo_set_study(int bits);

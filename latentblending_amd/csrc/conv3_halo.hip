@@ -324,6 +324,19 @@ static int halo_num_cus() {
     return n;
 }
 
+// work items of a launch and the grid that walks them: persistent = the largest multiple of the weight-slab period
+// (channel blocks, x4 parities for the 2x2 form) that fits the CUs, so that a block keeps one (channel block, parity)
+static void halo_grid(const LbGemmParams& p, int tw, int ks, long& items, long& grid) {
+    const int th = 256 / tw;
+    const long tiles = (long)(p.M / (p.Hin * p.Win)) * (p.Hin / th) * (p.Win / tw) * (ks == 2 ? 4 : 1);
+    const int n_blocks = (p.N + 127) / 128;
+    items = tiles * n_blocks;
+    const int period = n_blocks * (ks == 2 ? 4 : 1);
+    grid = items;
+    if (g_halo_persistent && period <= halo_num_cus() && items > halo_num_cus())
+        grid = (long)(halo_num_cus() / period) * period;
+}
+
 template <int BN, int TW, int KS = 3>
 static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
     constexpr int TH = 256 / TW;
@@ -335,15 +348,10 @@ static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
         allowed = true;
     }
-    const long tiles = (long)(p.M / (p.Hin * p.Win)) * (p.Hin / TH) * (p.Win / TW) * (KS == 2 ? 4 : 1);
-    const int n_blocks = (p.N + BN - 1) / BN;
-    const long nblk = tiles * n_blocks;
+    static_assert(BN == 128, "halo_grid assumes 128-channel blocks");
+    long nblk, grid;
+    halo_grid(p, TW, KS, nblk, grid);
     LB_REQUIRE(nblk < (1l << 30), "halo conv: too many tiles for one launch");
-    // persistent grid: the largest multiple of the weight-slab period (channel blocks, x4 parities) that fits the CUs
-    const int period = n_blocks * (KS == 2 ? 4 : 1);
-    long grid = nblk;
-    if (g_halo_persistent && period <= halo_num_cus() && nblk > halo_num_cus())
-        grid = (long)(halo_num_cus() / period) * period;
     LbGemmParams pk = p;
     pk.reserved_ = g_halo_study;
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS>), dim3((unsigned)grid), dim3(512), SMEM, stream, pk);
@@ -407,4 +415,19 @@ extern "C" int lb_conv3x3_halo_f16(const LbGemmParams* pp, void* stream) {
     LB_REQUIRE(p.ldw % 8 == 0 && p.ldx % 8 == 0 && (p.ldc % 4 == 0 || (p.flags & LB_GEMM_TRANS_OUT)),
                "lb_conv3x3_halo_f16: ldw / ldx multiples of 8, ldc multiple of 4");
     LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
+}
+
+// Host arithmetic of a halo launch (no device work): kind = 0 (not a halo launch), 3 (3x3 form) or 2 (2x2 sub-pixel form),
+// tile width, number of (tile [, parity], channel block) work items and the grid the launcher would use.
+extern "C" void lb_conv_halo_plan(const LbGemmParams* pp, int* kind, int* tile_w, long* items, long* grid) {
+    LbGemmParams p = *pp;
+    int k = 0, tw = 0;
+    if ((tw = lb_upconv_halo_eligible(p)) != 0) k = 2;
+    else if ((tw = lb_conv3x3_halo_eligible(p)) != 0) k = 3;
+    long it = 0, gr = 0;
+    if (k) halo_grid(p, tw, k, it, gr);
+    if (kind) *kind = k;
+    if (tile_w) *tile_w = tw;
+    if (items) *items = it;
+    if (grid) *grid = gr;
 }

@@ -632,3 +632,49 @@ def test_speculative_frontier_equals_sequential_under_skewed_metric(skew, cpu_ba
     assert spec.stats["frontier_rounds"] >= 3               # ... which costs the frontier several rounds
     assert spec.stats["speculation_evaluated"] >= 9
     assert spec.stats["speculation_evaluated"] - spec.stats.get("speculation_dropped", 0) == 9
+
+
+@pytest.mark.parametrize("B,H,W,Cin,N,ks", [(17, 512, 512, 128, 128, 3), (17, 64, 64, 320, 320, 3), (17, 16, 16, 1280, 1280, 3),
+                                            (2, 64, 64, 640, 320, 3), (17, 256, 256, 256, 256, 2), (3, 32, 32, 192, 640, 2),
+                                            (1, 16, 16, 64, 64, 3)])
+def test_halo_conv_persistent_work_split(B, H, W, Cin, N, ks):
+    """lb_conv_halo_plan + an emulation of the kernel's block -> work-item walk (csrc/conv3_halo.hip: XCD remap of the
+    block id, items bid, bid + G, ...): every (image, tile[, parity], channel block) item is processed exactly once and a
+    block keeps ONE channel block (and parity) for its whole life - what lets it keep its weight stream running across
+    tile boundaries."""
+    from latentblending_amd.hip import lib
+    p = lib.LbGemmParams()
+    p.conv, p.Hin, p.Win, p.Cin, p.Hout, p.Wout, p.stride, p.ups, p.ldx = 1, H, W, Cin, H, W, 1, 0, Cin
+    p.KH = p.KW = ks
+    p.pad = 1 if ks == 3 else 0
+    p.scatter = 2 if ks == 2 else 0
+    p.M, p.N, p.K = B * H * W, N, ks * ks * Cin
+    p.zero_page = 64                                     # (never dereferenced by the planner)
+    kind, tw, items, grid = ctypes.c_int(), ctypes.c_int(), ctypes.c_long(), ctypes.c_long()
+    lib.api.lb_conv_halo_plan(ctypes.byref(p), ctypes.byref(kind), ctypes.byref(tw), ctypes.byref(items), ctypes.byref(grid))
+    assert kind.value == ks and tw.value in (16, 32)
+    th = 256 // tw.value
+    n_blocks = (N + 127) // 128
+    par = 4 if ks == 2 else 1
+    assert items.value == B * (H // th) * (W // tw.value) * par * n_blocks
+    G = grid.value
+    assert 0 < G <= items.value and (G == items.value or (G <= 256 and G % (n_blocks * par) == 0))
+    seen = set()
+    for blk in range(G):
+        q, r, xcd, idx = G // 8, G % 8, blk % 8, blk // 8
+        bid = (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + idx
+        keys = set()
+        item = bid
+        while item < items.value:
+            block_n = item % n_blocks
+            tile = item // n_blocks
+            parity = tile & 3 if ks == 2 else 0
+            keys.add((block_n, parity))
+            assert item not in seen
+            seen.add(item)
+            item += G
+        assert len(keys) <= 1, "a persistent block changed its weight slab"
+        # the kernel derives (block_n, parity) once, from the block id: same thing as from any of its items
+        if keys:
+            assert keys == {(bid % n_blocks, (bid // n_blocks) & 3 if ks == 2 else 0)}
+    assert len(seen) == items.value
