@@ -458,7 +458,8 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
     const int bn = tile == 5 ? 256 : ((tile == 1 || tile == 4 || tile == 7) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
-    if (!geglu && p.partial != nullptr && !(p.flags & LB_GEMM_LN_A)) {     // (LN_A: a block must see whole rows of A)
+    // (LN_A: a block must see whole rows of A; ROW_STATS: the statistics are taken where the final values are formed)
+    if (!geglu && p.partial != nullptr && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_ROW_STATS))) {
         const int k_tiles = (p.K + BK - 1) / BK;
         if (g_force_splitk) splitk = g_force_splitk;
         else if (nblk <= 256) {
@@ -512,6 +513,13 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
                    "lb_gemm_f16: LB_GEMM_LN_A needs a plain / GEGLU GEMM of the direct-to-LDS family with ln_colsum");
         LB_REQUIRE(p.lda >= p.K && !(p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: LB_GEMM_LN_A normalises whole rows of A");
     }
+    if (p.flags & LB_GEMM_ROW_STATS) {
+        LB_REQUIRE(!p.conv && p.row_stats != nullptr && p.zero_page != nullptr && g_variant == 1 && p.N % 32 == 0 &&
+                       !(p.flags & (LB_GEMM_GEGLU | LB_GEMM_TRANS_OUT | LB_GEMM_OUT_F32 | LB_GEMM_LN_A)),
+                   "lb_gemm_f16: LB_GEMM_ROW_STATS needs a plain fp16-out GEMM of the direct-to-LDS family, N % 32 == 0, row_stats");
+    }
+    if ((p.flags & LB_GEMM_LN_A) && p.row_stats != nullptr)
+        LB_REQUIRE(p.ln_nslots > 0 && p.ln_nslots * 32 == p.K, "lb_gemm_f16: LB_GEMM_LN_A with row_stats needs ln_nslots = K / 32");
     if (p.alpha == 0.f) p.alpha = 1.f;
     if (p.scatter == 2) {       // all four sub-pixel parities in one launch: only the halo kernel implements it
         LB_REQUIRE(lb_upconv_halo_eligible(p) != 0, "lb_gemm_f16: scatter = 2 needs Cin % 64 == 0, W % 16 == 0, stacked [4][N][K] weights");
@@ -526,7 +534,9 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     int stages = g_stages;
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
-        if (stages == 0) stages = (tile == 3 || tile == 4 || tile == 7) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
+        const bool row_stat_kernels = (p.flags & LB_GEMM_ROW_STATS) || ((p.flags & LB_GEMM_LN_A) && p.row_stats != nullptr);
+        if (stages == 0 || row_stat_kernels)
+            stages = (tile == 3 || tile == 4 || tile == 7) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

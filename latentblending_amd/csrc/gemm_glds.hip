@@ -56,7 +56,10 @@ __device__ __forceinline__ void ln_accumulate(const f16x8 (&af)[TM], float (&sum
 // 170 tiles of 256x128 (2/3 of the chip, one round) but 230 tiles of 192x128 at 3/4 of the work each.  Its weight
 // tile (128 rows) is not a multiple of the 48 rows one round of its 384 threads stages: the third round is half
 // masked (rows >= BN fetch the zero page into 16 padding rows of the stage).
-template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, bool LNA = false>
+// LNA: 0 none; 1 LayerNorm of A folded in, row statistics accumulated from the A fragments inside the K loop; 2 folded
+// in with the statistics read from p.row_stats (left there by the epilogue of the GEMM that produced A, STATS).
+// STATS: this GEMM's epilogue writes the row statistics of its output (LB_GEMM_ROW_STATS).
+template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, int LNA = 0, bool STATS = false>
 __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmParams p) {
     constexpr int NT = WMW * 128;           // threads per block
     constexpr int RPI = NT / 8;             // tile rows covered by one round of wave instructions
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 read_frags(st, s, af, wf);
-                if (LNA) ln_accumulate<TM>(af, ln_sum, ln_sq);
+                if (LNA == 1) ln_accumulate<TM>(af, ln_sum, ln_sq);
                 mma_rows(af, wf, 0, TM);
             }
         } else {
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a0, w0, 0, HM);
             read_frags(st, 1, a1, w1);
-            if (LNA) ln_accumulate<TM>(a0, ln_sum, ln_sq);
+            if (LNA == 1) ln_accumulate<TM>(a0, ln_sum, ln_sq);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int idx = 0; idx < NL; ++idx)
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
             for (int idx = 0; idx < NL; ++idx)
                 if (idx * 4 / NL == 3) issue_one(idx, base, k_ok);
             advance_k();
-            if (LNA) ln_accumulate<TM>(a1, ln_sum, ln_sq);
+            if (LNA == 1) ln_accumulate<TM>(a1, ln_sum, ln_sq);
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a1, w1, HM, TM);
         }
@@ -318,7 +321,20 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
         const float inv_k = 1.f / (float)p.K;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float su = ln_sum[i], sq = ln_sq[i];
+            float su, sq;
+            if (LNA == 1) {
+                su = ln_sum[i];
+                sq = ln_sq[i];
+            } else {        // the producer's 32-column slots of this row, four interleaved subsets (one per g), fixed order
+                const int m = m0 + wave_m * WROWS + i * 16 + l16;
+                const float2* st = reinterpret_cast<const float2*>(p.row_stats) + (m < p.M ? m : p.M - 1);
+                su = sq = 0.f;
+                for (int sl = g; sl < p.ln_nslots; sl += 4) {
+                    const float2 v = st[(long)sl * p.M];
+                    su += v.x;
+                    sq += v.y;
+                }
+            }
             su += __shfl_xor(su, 16, LB_WAVE); sq += __shfl_xor(sq, 16, LB_WAVE);
             su += __shfl_xor(su, 32, LB_WAVE); sq += __shfl_xor(sq, 32, LB_WAVE);
             const float mean = su * inv_k;
@@ -332,6 +348,11 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
                                                            n0 + wave_n * (BN / 64) * 16 + 4 * g, &ln);
         return;
     }
+    if (STATS) {
+        lb_gemm_tile_epilogue_stats<TM, TN>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
+                                            n0 + wave_n * (BN / 64) * 16 + 4 * g);
+        return;
+    }
     lb_gemm_tile_epilogue<TM, TN, GEGLU>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
                                          n0 + wave_n * (BN / 64) * 16 + 4 * g);
 }
@@ -342,22 +363,40 @@ constexpr int glds_stage_rows() {                       // A rows + weight rows 
     return BM + WI * RPI;
 }
 
-template <int BM, int BN, int S, int WMW = 2>
+// EXTRA: the row-statistics kernels (LNA = 2 consumers, STATS producers) exist for this (tile, stages) pair - only the
+// default stage count of every tile, to keep the number of instantiations down; lb_gemm_f16 picks that stage count
+// whenever a launch asks for them.
+template <int BM, int BN, int S, int WMW = 2, bool EXTRA = false>
 static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t smem = (size_t)S * glds_stage_rows<BM, BN, WMW>() * BK * sizeof(f16);
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
     const dim3 block(WMW * 128);
     const bool lna = (p.flags & LB_GEMM_LN_A) != 0;
+    const bool from_stats = lna && p.row_stats != nullptr;
+    const bool stats = (p.flags & LB_GEMM_ROW_STATS) != 0;
+    if constexpr (EXTRA) {
+        if (stats) {
+            hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, true>), grid, block, smem, stream, p);
+            return 0;
+        }
+        if (from_stats) {
+            if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 2>), grid, block, smem, stream, p);
+            else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 2>), grid, block, smem, stream, p);
+            return 0;
+        }
+    } else if (stats || from_stats) {
+        LB_REQUIRE(false, "lb_gemm_f16: row-statistics kernels exist for the default stage count of a tile only");
+    }
     if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>), grid, block, smem, stream, p);
-    else if (geglu && lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, true>), grid, block, smem, stream, p);
+    else if (geglu && lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 1>), grid, block, smem, stream, p);
     else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>), grid, block, smem, stream, p);
-    else if (lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, true>), grid, block, smem, stream, p);
+    else if (lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 1>), grid, block, smem, stream, p);
     else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW>), grid, block, smem, stream, p);
     return 0;
 }
 
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside of any stream capture
-template <int BM, int BN, int S, int WMW = 2>
+template <int BM, int BN, int S, int WMW = 2, bool EXTRA = false>
 static void allow_lds() {
     const int smem = S * glds_stage_rows<BM, BN, WMW>() * BK * (int)sizeof(f16);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>),
@@ -366,44 +405,52 @@ static void allow_lds() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if constexpr (EXTRA) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
 }
 
 void lb_gemm_glds_init() {
     static bool done = false;
     if (done) return;
     done = true;
-    allow_lds<128, 128, 2>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
-    allow_lds<128, 64, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
-    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3>(); allow_lds<64, 64, 4>();
-    allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4>();
-    allow_lds<256, 256, 2, 4>();
-    allow_lds<192, 128, 3, 3>();
+    allow_lds<128, 128, 2, 2, true>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
+    allow_lds<128, 64, 2, 2, true>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
+    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2, true>(); allow_lds<64, 64, 4>();
+    allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4, true>();
+    allow_lds<256, 256, 2, 4, true>();
+    allow_lds<192, 128, 3, 3, true>();
 }
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave),
 // 7 = 192x128 (6 waves, 3-stage ring); stages: 2..4 (0 = default for the tile)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
-    if (tile == 7) return launch_glds_variant<192, 128, 3, 3>(p, grid, stream);            // 3 x 42 KiB
-    if (tile == 5) return launch_glds_variant<256, 256, 2, 4>(p, grid, stream);     // 128 KiB: two stages only
+    if (tile == 7) return launch_glds_variant<192, 128, 3, 3, true>(p, grid, stream);            // 3 x 42 KiB
+    if (tile == 5) return launch_glds_variant<256, 256, 2, 4, true>(p, grid, stream);     // 128 KiB: two stages only
     if (tile == 4) {
-        if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);
+        if (stages == 3) return launch_glds_variant<256, 128, 3, 4, true>(p, grid, stream);
         return launch_glds_variant<256, 128, 2, 4>(p, grid, stream);
     }
     if (tile == 1) {
-        if (stages == 2) return launch_glds_variant<128, 128, 2>(p, grid, stream);
+        if (stages == 2) return launch_glds_variant<128, 128, 2, 2, true>(p, grid, stream);
         if (stages == 4) return launch_glds_variant<128, 128, 4>(p, grid, stream);
         return launch_glds_variant<128, 128, 3>(p, grid, stream);
     }
     if (tile == 2) {
-        if (stages == 2) return launch_glds_variant<128, 64, 2>(p, grid, stream);
+        if (stages == 2) return launch_glds_variant<128, 64, 2, 2, true>(p, grid, stream);
         if (stages == 4) return launch_glds_variant<128, 64, 4>(p, grid, stream);
         return launch_glds_variant<128, 64, 3>(p, grid, stream);
     }
     if (stages == 2) return launch_glds_variant<64, 64, 2>(p, grid, stream);
-    if (stages == 3) return launch_glds_variant<64, 64, 3>(p, grid, stream);
+    if (stages == 3) return launch_glds_variant<64, 64, 3, 2, true>(p, grid, stream);
     return launch_glds_variant<64, 64, 4>(p, grid, stream);
 }

@@ -32,7 +32,7 @@ class LbGemmParams(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
         ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
-        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_nslots", C.c_int), ("row_stats", C.c_void_p),
     ]
 
 
@@ -46,7 +46,7 @@ class LbAttnParams(C.Structure):
 
 
 GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU, GEMM_LN_A = 1, 2, 4, 8, 16, 32, 64
-GEMM_QUICK_GELU, GEMM_GELU = 128, 256
+GEMM_QUICK_GELU, GEMM_GELU, GEMM_ROW_STATS = 128, 256, 512
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 

@@ -61,16 +61,21 @@ def _pad(n: int, m: int) -> int:
 
 
 class NativeUNet:
-    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm: bool = False):
+    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm=False):
         """``fuse_layernorm``: fold the three LayerNorms of every transformer block into the GEMMs that consume them
-        (LB_GEMM_LN_A: no LayerNorm launch, no normalised copy of the hidden state).  OFF by default: on MI355X the
-        row statistics accumulated inside the K loop (64 v_dot2 per K-tile and wave) cost the MFMA loop more than the
-        6 us LayerNorm launch they replace (profiles/r02_ln_gemm_bench.txt: QKV 57.1 + 6.4 us separate vs 70.0 us
-        fused at B=17; GEGLU 132 + 6 vs 166) - kept as a tested option for tile shapes / chips where the VALU is idle."""
+        (LB_GEMM_LN_A: no LayerNorm launch, no normalised copy of the hidden state).
+        ``True``: row statistics accumulated inside the consumer's K loop.  OFF by default: on MI355X the 64 v_dot2 per
+        K-tile and wave cost the MFMA loop more than the 6 us LayerNorm launch they replace
+        (profiles/r02_ln_gemm_bench.txt: QKV 57.1 + 6.4 us separate vs 70.0 us fused at B=17; GEGLU 132 + 6 vs 166).
+        ``"stats"``: the GEMM that PRODUCES the hidden state (proj_in, the attention output projections, the
+        feed-forward output) writes per-row (sum, sum of squares) of what it stores from its epilogue
+        (LB_GEMM_ROW_STATS) and the consumer only applies the algebraic fold; producers that the planner runs split-K
+        (B=2 feed-forward outputs) keep a stand-alone LayerNorm behind them."""
         assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
+        assert fuse_layernorm in (False, True, "stats")
         self.cfg, self.device = cfg, torch.device(device)
-        self.fuse_layernorm = bool(fuse_layernorm)
-        self.keep_ln_weights = not self.fuse_layernorm
+        self.fuse_layernorm = fuse_layernorm
+        self.keep_ln_weights = fuse_layernorm is not True
         self.w: Dict[str, torch.Tensor] = {}
         self.temb_slices: Dict[str, Tuple[int, int]] = {}      # resnet -> (offset, cout) in the fused projection
         self.ctx_slices: Dict[str, Tuple[int, int]] = {}       # transformer block -> (offset, C) in fused ctx K / V
@@ -334,16 +339,23 @@ class UNetProgram:
         em.groupnorm(x, n, w[p + ".norm.weight"], w[p + ".norm.bias"], B=B, HW=S, C_=c, eps=1e-6, silu=False,
                      groups=self.net.cfg.norm_groups)
         h = ar.alloc((M, c))
-        em.gemm(n, w[p + ".proj_in.weight"], h, M=M, bias=w[p + ".proj_in.bias"])
+        mode = self.net.fuse_layernorm
+        # "stats" mode: the producers of h leave its row statistics in `st`; a producer the planner would run split-K
+        # (its final values are formed by the reduce kernel) cannot, and the LayerNorm behind it stays a launch
+        st = ar.alloc((c // 32, M, 2), F32) if mode == "stats" and c % 32 == 0 else None
+        can_short = st is not None and em.plan(M, c, c)[1] == 1            # proj_in / attention output projections (K = c)
+        can_long = st is not None and em.plan(M, c, 4 * c)[1] == 1         # feed-forward output (K = 4c)
+        em.gemm(n, w[p + ".proj_in.weight"], h, M=M, bias=w[p + ".proj_in.bias"], row_stats=st if can_short else None)
+        have_stats = can_short
         ar.release(n)
         for d in range(depth):
             b = f"{p}.transformer_blocks.{d}"
             # --- self attention ---
-            fuse = self.net.fuse_layernorm
+            fuse = mode is True or have_stats
             qkv = ar.alloc((M, 3 * c))
-            if fuse:        # LayerNorm folded into the projection: statistics from the A fragments, affine in the epilogue
+            if fuse:        # LayerNorm folded into the projection: affine in the epilogue, statistics from the A fragments or from `st`
                 em.gemm(h, w[b + ".attn1.qkv_ln.weight"], qkv, M=M, bias=w[b + ".attn1.qkv_ln.bias"],
-                        ln=(w[b + ".attn1.qkv_ln.colsum"], 1e-5))
+                        ln=(w[b + ".attn1.qkv_ln.colsum"], 1e-5), ln_stats=st if have_stats else None)
             else:
                 ln = ar.alloc((M, c))
                 em.layernorm(h, ln, w[b + ".norm1.weight"], w[b + ".norm1.bias"], M=M, C_=c)
@@ -353,13 +365,16 @@ class UNetProgram:
             em.attention(qkv.data_ptr(), qkv.data_ptr() + c * 2, qkv.data_ptr() + 2 * c * 2, a, B=B, H=heads, Sq=S,
                          Skv=S, valid=S, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c)
             ar.release(qkv)
-            em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h)
+            em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h,
+                    row_stats=st if can_short else None)
+            have_stats = can_short
             ar.release(a)
             # --- cross attention (K / V^T of the text context come from the conditioning program) ---
+            fuse = mode is True or have_stats
             q = ar.alloc((M, c))
             if fuse:
                 em.gemm(h, w[b + ".attn2.to_q_ln.weight"], q, M=M, bias=w[b + ".attn2.to_q_ln.bias"],
-                        ln=(w[b + ".attn2.to_q_ln.colsum"], 1e-5))
+                        ln=(w[b + ".attn2.to_q_ln.colsum"], 1e-5), ln_stats=st if have_stats else None)
             else:
                 ln = ar.alloc((M, c))
                 em.layernorm(h, ln, w[b + ".norm2.weight"], w[b + ".norm2.bias"], M=M, C_=c)
@@ -371,21 +386,30 @@ class UNetProgram:
                          self.ctx_kv.data_ptr() + (self.net.n_ctx + off) * 2, a, B=B, H=heads, Sq=S, Skv=CTX_PAD,
                          valid=CTX_TOKENS, ldq=c, ldk=2 * self.net.n_ctx, ldv=2 * self.net.n_ctx, ldo=c)
             ar.release(q)
-            em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h)
+            em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h,
+                    row_stats=st if can_short else None)
+            have_stats = can_short
             ar.release(a)
             # --- GEGLU feed-forward ---
+            fuse = mode is True or have_stats
             ff = ar.alloc((M, 4 * c))
             if fuse:
                 em.gemm(h, w[b + ".ff.net.0.proj_ln.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj_ln.bias"],
-                        flags=lib.GEMM_GEGLU, ln=(w[b + ".ff.net.0.proj_ln.colsum"], 1e-5))
+                        flags=lib.GEMM_GEGLU, ln=(w[b + ".ff.net.0.proj_ln.colsum"], 1e-5),
+                        ln_stats=st if have_stats else None)
             else:
                 ln = ar.alloc((M, c))
                 em.layernorm(h, ln, w[b + ".norm3.weight"], w[b + ".norm3.bias"], M=M, C_=c)
                 em.gemm(ln, w[b + ".ff.net.0.proj.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj.bias"],
                         flags=lib.GEMM_GEGLU)
                 ar.release(ln)
-            em.gemm(ff, w[b + ".ff.net.2.weight"], h, M=M, bias=w[b + ".ff.net.2.bias"], residual=h)
+            last = d == depth - 1                       # (proj_out follows: nobody reads the statistics)
+            em.gemm(ff, w[b + ".ff.net.2.weight"], h, M=M, bias=w[b + ".ff.net.2.bias"], residual=h,
+                    row_stats=st if can_long and not last else None)
+            have_stats = can_long and not last
             ar.release(ff)
+        if st is not None:
+            ar.release(st)
         out = ar.alloc((B, H, W, c))
         em.gemm(h, w[p + ".proj_out.weight"], out, M=M, bias=w[p + ".proj_out.bias"], residual=x)
         ar.release(h)

@@ -431,6 +431,52 @@ def test_gemm_layernorm_fused(case, tile, results_log):
     check_close(results_log, f"gemm_ln_fused_{'_'.join(map(str, case))}_tile{tile}", got, ref, rel=3e-3, frac=2 ** -7)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("case", [(4352, 1280, 1280), (1000, 640, 320), (512, 1280, 5120)])
+def test_gemm_row_stats_and_fold(case, tile, results_log):
+    """LB_GEMM_ROW_STATS + LB_GEMM_LN_A(row_stats): the producer GEMM (bias + residual, written in place like the UNet's
+    output projections) leaves per-row (sum, sum of squares) of the fp16 values it stores, per 32-column slot; the
+    consumer folds the LayerNorm of those rows algebraically from them.  Checked: the statistics themselves against
+    torch on the stored tensor, and producer -> consumer against torch Linear -> LayerNorm -> Linear (-> GEGLU)."""
+    o, l = ops(), lib()
+    M, N, K = case
+    a = rnd(M, K, seed=181)
+    w1 = rnd(N, K, seed=182, scale=K ** -0.5)
+    b1 = rnd(N, seed=183, dtype=torch.float32)
+    res = rnd(M, N, seed=184) * 1.5 + rnd(M, 1, seed=185) * 3.0        # rows with a common offset (mean >> 0)
+    h = res.to(DEV).clone()
+    st = torch.full((N // 32, M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        o.gemm(a.to(DEV), w1.to(DEV), bias=b1.to(DEV), residual=h, out=h, row_stats=st)
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    ref_h = a.float() @ w1.float().t() + b1 + res.float()
+    check_close(results_log, f"gemm_rowstats_out_{M}_{N}_{K}_tile{tile}", h, ref_h, rel=3e-3)
+    hs = h.float().cpu().reshape(M, N // 32, 32)
+    s_ref, q_ref = hs.sum(-1).t(), (hs * hs).sum(-1).t()                # [slots, M] of the STORED values
+    assert torch.isfinite(st).all(), "a statistics slot was not written"
+    assert torch.allclose(st[..., 0].cpu(), s_ref, rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1].cpu(), q_ref, rtol=1e-4, atol=1e-2)
+    # consumer: LayerNorm(h) -> Linear (and GEGLU) with the statistics from the buffer
+    for geglu in (False, True):
+        N2 = 640 if geglu else 384
+        w2 = rnd(N2, N, seed=186, scale=N ** -0.5)
+        b2 = rnd(N2, seed=187, dtype=torch.float32)
+        gamma = 1.0 + 0.2 * rnd(N, seed=188, dtype=torch.float32)
+        beta = 0.1 * rnd(N, seed=189, dtype=torch.float32)
+        ref = F.layer_norm(h.float().cpu(), (N,), gamma, beta, 1e-5) @ w2.float().t() + b2
+        if geglu:
+            hh, gt = ref.chunk(2, dim=-1)
+            ref = hh * F.gelu(gt)
+        wf, colsum, bf = o.fold_layernorm(w2, b2, gamma, beta)
+        l.api.lb_gemm_set_tuning(tile, 0)
+        try:
+            got = o.gemm(h, wf.to(DEV), bias=bf.to(DEV), flags=l.GEMM_GEGLU if geglu else 0, ln=(colsum.to(DEV), 1e-5), ln_stats=st)
+        finally:
+            l.api.lb_gemm_set_tuning(0, 0)
+        check_close(results_log, f"gemm_ln_from_stats_{M}_{N}_{K}_{int(geglu)}_tile{tile}", got, ref, rel=3e-3, frac=2 ** -7)
+
+
 # ------------------------------------------------------------------ attention ----------------
 @pytest.mark.parametrize("case", [(1, 10, 1024, 1024, 1024), (2, 20, 256, 256, 256), (2, 5, 100, 80, 77),
                                   (1, 2, 64, 64, 64), (1, 10, 4096, 80, 77), (3, 4, 200, 200, 200)])
