@@ -70,7 +70,10 @@ class NativeUNet:
         ``"stats"``: the GEMM that PRODUCES the hidden state (proj_in, the attention output projections, the
         feed-forward output) writes per-row (sum, sum of squares) of what it stores from its epilogue
         (LB_GEMM_ROW_STATS) and the consumer only applies the algebraic fold; producers that the planner runs split-K
-        (B=2 feed-forward outputs) keep a stand-alone LayerNorm behind them."""
+        (B=2 feed-forward outputs) keep a stand-alone LayerNorm behind them.  Also measured SLOWER
+        (profiles/r02_ln_stats_ab.txt: forward at B=17 38.6 -> 42.3 ms with 703 instead of 913 launches, B=2 12.4 -> 12.9):
+        the cost is not the in-loop statistics but the consumer's epilogue, which fetches the statistics and the column
+        sums row by row behind the K loop (an exposed L2 round trip per row group and block).  Both stay tested options."""
         assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
         assert fuse_layernorm in (False, True, "stats")
         self.cfg, self.device = cfg, torch.device(device)
