@@ -1,4 +1,4 @@
-"""`gloo` tests of the branch farm on CPU: 2 / 3 ranks run the SPMD engine on the tiny oracle pipe, split every
+"""`gloo` tests of the branch farm on CPU: 2 / 3 / 4 ranks run the SPMD engine on the tiny oracle pipe, split every
 speculative round between them (unevenly at world 3), and must all end with exactly the tree the sequential
 reference produced (tests/golden/tree.json: fractions, similarities, latents, frames); chained transitions with a
 recycled anchor (swap_forward + recycle_img1) must equal the farm-less run; ranks holding different plans must
@@ -63,9 +63,10 @@ def _worker(rank, world, port, run, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("run,world", [(0, 2), (2, 2), (0, 3)])
+@pytest.mark.parametrize("run,world", [(0, 2), (2, 2), (0, 3), (1, 4)])
 def test_branch_farm_reproduces_sequential_tree(run, world, tmp_path):
-    """world 3 splits rounds of 4 branches 2 / 1 / 1 (and later rounds leave ranks without a branch)."""
+    """world 3 splits rounds of 4 branches 2 / 1 / 1 (and later rounds leave ranks without a branch); world 4 runs a
+    3-branch tree, so one rank never owns a mid branch."""
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, run, str(tmp_path)), nprocs=world, join=True)
