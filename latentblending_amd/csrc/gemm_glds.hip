@@ -424,8 +424,8 @@ void lb_gemm_glds_init() {
     if (done) return;
     done = true;
     allow_lds<128, 128, 2, 2, true>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
-    allow_lds<128, 64, 2, 2, true>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
-    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2, true>(); allow_lds<64, 64, 4>();
+    allow_lds<128, 64, 2, 2, true>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>(); allow_lds<128, 64, 6>();
+    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2, true>(); allow_lds<64, 64, 4>(); allow_lds<64, 64, 6>(); allow_lds<64, 64, 8>();
     allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4, true>();
     allow_lds<256, 256, 2, 4, true>();
     allow_lds<192, 128, 3, 3, true>();
@@ -448,9 +448,12 @@ int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, 
     if (tile == 2) {
         if (stages == 2) return launch_glds_variant<128, 64, 2, 2, true>(p, grid, stream);
         if (stages == 4) return launch_glds_variant<128, 64, 4>(p, grid, stream);
+        if (stages >= 6) return launch_glds_variant<128, 64, 6>(p, grid, stream);       // 6 x 24 KiB: one block per CU
         return launch_glds_variant<128, 64, 3>(p, grid, stream);
     }
     if (stages == 2) return launch_glds_variant<64, 64, 2>(p, grid, stream);
     if (stages == 3) return launch_glds_variant<64, 64, 3, 2, true>(p, grid, stream);
+    if (stages == 6) return launch_glds_variant<64, 64, 6>(p, grid, stream);             // 96 KiB: one block per CU,
+    if (stages >= 8) return launch_glds_variant<64, 64, 8>(p, grid, stream);             // 128 KiB: latency-bound small grids
     return launch_glds_variant<64, 64, 4>(p, grid, stream);
 }

@@ -221,11 +221,13 @@ class StableDiffusionXLPipeline:
         pe, pooled = embed(text)
         if not do_classifier_free_guidance:
             return pe, None, pooled, None
-        neg = negative_prompt[0] if isinstance(negative_prompt, (list, tuple)) and negative_prompt else negative_prompt
-        if neg:
-            npe, npooled = embed(neg)
-        else:
-            npe, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
+        # diffusers' StableDiffusionXLPipeline.encode_prompt: zeros ONLY for ``negative_prompt is None`` (with the SDXL
+        # checkpoints' force_zeros_for_empty_prompt); any given negative prompt - including the reference holder's default
+        # "" (/root/reference/latentblending/diffusers_holder.py:23,87) - is tokenised and ENCODED
+        if negative_prompt is None:
+            return pe, torch.zeros_like(pe), pooled, torch.zeros_like(pooled)
+        neg = negative_prompt[0] if isinstance(negative_prompt, (list, tuple)) else negative_prompt
+        npe, npooled = embed(neg if neg is not None else "")
         return pe, npe, pooled, npooled
 
     def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):

@@ -149,12 +149,14 @@ class StableDiffusionXLPipeline:
         pooled = synthetic_embedding(text, (1, c.pooled_dim), self.dtype, 2)
         if not do_classifier_free_guidance:
             return pe, None, pooled, None
-        neg = negative_prompt[0] if isinstance(negative_prompt, (list, tuple)) and negative_prompt else negative_prompt
-        if neg:
-            npe = synthetic_embedding(neg, (1, 77, c.cross_dim), self.dtype, 1)
-            npooled = synthetic_embedding(neg, (1, c.pooled_dim), self.dtype, 2)
-        else:
-            npe, npooled = torch.zeros_like(pe), torch.zeros_like(pooled)
+        # diffusers semantics: zero embeddings only when negative_prompt is None (force_zeros_for_empty_prompt); a given
+        # negative prompt, "" included (the reference holder's default), is encoded like any other text
+        if negative_prompt is None:
+            return pe, torch.zeros_like(pe), pooled, torch.zeros_like(pooled)
+        neg = negative_prompt[0] if isinstance(negative_prompt, (list, tuple)) else negative_prompt
+        neg = "" if neg is None else neg
+        npe = synthetic_embedding(neg, (1, 77, c.cross_dim), self.dtype, 1)
+        npooled = synthetic_embedding(neg, (1, c.pooled_dim), self.dtype, 2)
         return pe, npe, pooled, npooled
 
     def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):

@@ -678,3 +678,25 @@ def test_halo_conv_persistent_work_split(B, H, W, Cin, N, ks):
         if keys:
             assert keys == {(bid % n_blocks, (bid // n_blocks) & 3 if ks == 2 else 0)}
     assert len(seen) == items.value
+
+
+def test_negative_prompt_semantics_follow_diffusers(cpu_backend):
+    """diffusers' encode_prompt zeroes the negative embeddings only for ``negative_prompt is None``; the reference holder
+    passes its default "" (diffusers_holder.py:23,87), which is therefore ENCODED.  Both the oracle pipe and the holder on
+    top of it must behave that way (the native pipe has the same logic: tests/test_native_gpu.py)."""
+    from latentblending_amd import DiffusersHolder
+    p = tiny_pipe(turbo=False)
+    pe, npe, pooled, npooled = p.encode_prompt("a reef", negative_prompt=None)
+    assert float(npe.abs().max()) == 0 and float(npooled.abs().max()) == 0
+    for neg in ("", "blurry", ["blurry"]):
+        _, npe, _, npooled = p.encode_prompt("a reef", negative_prompt=neg)
+        assert float(npe.abs().max()) > 0 and float(npooled.abs().max()) > 0
+    e1 = p.encode_prompt("a reef", negative_prompt="blurry")[1]
+    e2 = p.encode_prompt("a reef", negative_prompt=["blurry"])[1]
+    assert torch.equal(e1, e2) and not torch.equal(e1, p.encode_prompt("a reef", negative_prompt="")[1])
+    dh = DiffusersHolder(p)
+    dh.guidance_scale = 4.0
+    emb = dh.get_text_embedding("a reef")
+    assert torch.equal(emb[1], p.encode_prompt("x", negative_prompt="")[1])          # holder default "" -> encoded ""
+    dh.set_negative_prompt(["ugly", "ignored second entry"])
+    assert torch.equal(dh.get_text_embedding("a reef")[1], p.encode_prompt("x", negative_prompt="ugly")[1])

@@ -524,3 +524,53 @@ def test_prompt_conditioning_through_the_pipe(results_log):
     imgs = be.run_transition(fixed_seeds=[5, 6])
     assert len(imgs) == 5
     results_log["prompt_conditioning_pipe"] = {"frames": len(imgs)}
+
+
+def test_encode_prompt_negative_semantics_match_diffusers_assembly(results_log):
+    """The full 4-tuple of ``encode_prompt`` against the assembly diffusers' StableDiffusionXLPipeline.encode_prompt builds
+    from transformers' towers (hidden_states[-2] of CLIPTextModel | CLIPTextModelWithProjection concatenated, pooled =
+    text_embeds of the second tower), for the four negative-prompt cases: ``None`` -> zeros (force_zeros_for_empty_prompt),
+    ``""`` (the reference holder's default, diffusers_holder.py:23,87) -> the ENCODED empty prompt, a string, a list."""
+    n = native()
+    c1 = n.CLIPTextConfig(vocab_size=2000, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                          bos_token_id=1998, eos_token_id=1999, pad_token_id=1999)
+    c2 = n.CLIPTextConfig(vocab_size=2000, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                          hidden_act="gelu", projection_dim=128, bos_token_id=1998, eos_token_id=1999, pad_token_id=0)
+    hf1, hf2 = _hf_clip(c1, 3), _hf_clip(c2, 4)
+    t1 = n.NativeCLIPText(c1, n.DictProvider({k: v.detach() for k, v in hf1.state_dict().items()}), DEV)
+    t2 = n.NativeCLIPText(c2, n.DictProvider({k: v.detach() for k, v in hf2.state_dict().items()}), DEV)
+    enc = n.NativeTextEncoders(t1, t2, allow_synthetic=True)
+    ucfg, vcfg = R.tiny_unet_cfg(), R.tiny_vae_cfg()
+    pipe = n.NativeSDXLPipe(turbo=False, unet_cfg=n.UNetConfig(**dataclasses.asdict(ucfg)),
+                            vae_cfg=n.VAEConfig(**dataclasses.asdict(vcfg)), text_encoder_fn=enc.encode, allow_synthetic=True)
+
+    def assembly(text):
+        with torch.no_grad():
+            o1 = hf1(input_ids=enc.tok1(text), output_hidden_states=True)
+            o2 = hf2(input_ids=enc.tok2(text), output_hidden_states=True)
+        return torch.cat([o1.hidden_states[-2], o2.hidden_states[-2]], dim=-1), o2.text_embeds
+
+    prompt = "photo of a reef, incredible detail"
+    ref_pe, ref_pool = assembly(prompt)
+    worst = 0.0
+    for neg in (None, "", "blurry, ugly", ["blurry, ugly"]):
+        pe, npe, pooled, npooled = pipe.encode_prompt(prompt=prompt, prompt_2=prompt, do_classifier_free_guidance=True,
+                                                      negative_prompt=neg, negative_prompt_2=neg)
+        assert pe.shape == (1, 77, 256) and npe.shape == pe.shape and pooled.shape == npooled.shape == (1, 128)
+        worst = max(worst, rel_l2(pe, ref_pe), rel_l2(pooled, ref_pool))
+        if neg is None:
+            assert float(npe.abs().max()) == 0.0 and float(npooled.abs().max()) == 0.0
+        else:
+            want_pe, want_pool = assembly(neg[0] if isinstance(neg, list) else neg)
+            assert float(npe.abs().max()) > 0, "a given negative prompt (\"\" included) is encoded, not zeroed"
+            worst = max(worst, rel_l2(npe, want_pe), rel_l2(npooled, want_pool))
+    # the holder's default negative prompt is "" -> what a CFG run conditions on is the encoded empty prompt
+    from latentblending_amd import DiffusersHolder
+    dh = DiffusersHolder(pipe)
+    dh.guidance_scale = 4.0
+    emb = dh.get_text_embedding(prompt)
+    want_pe, want_pool = assembly("")
+    worst = max(worst, rel_l2(emb[1], want_pe), rel_l2(emb[3], want_pool))
+    results_log["encode_prompt_4tuple_vs_transformers_assembly"] = worst
+    print(f"[parity] encode_prompt 4-tuple vs transformers assembly (4 negative-prompt cases + holder default): worst rel_l2={worst:.3e}")
+    assert worst <= 5e-3

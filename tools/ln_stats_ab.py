@@ -34,7 +34,8 @@ def main():
     cdir = os.environ.get("LB_SYNTH_CACHE")
     cfile = os.path.join(cdir, "lb_synth_seed0.pt") if cdir else None
     outs = {}
-    for mode in (False, "stats"):
+    modes = [False] + [{"true": True, "stats": "stats"}[a] for a in sys.argv[1:] if a in ("true", "stats")] if len(sys.argv) > 1 else [False, "stats"]
+    for mode in modes:
         t0 = time.time()
         prov = N.SyntheticProvider(0, cache_file=cfile)
         net = N.NativeUNet(N.UNetConfig(), prov, DEV, fuse_layernorm=mode)
@@ -57,8 +58,9 @@ def main():
         del net
         torch.cuda.empty_cache()
     for B in (2, 17):
-        a, b = outs[(False, B)], outs[("stats", B)]
-        print(f"B={B}: rel-L2 between the two modes {float((a - b).norm() / a.norm()):.2e}")
+        for mode in modes[1:]:
+            a, b = outs[(False, B)], outs[(mode, B)]
+            print(f"B={B}: rel-L2 between default and mode={mode!r} {float((a - b).norm() / a.norm()):.2e}")
 
 
 if __name__ == "__main__":
