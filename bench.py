@@ -65,7 +65,31 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (cfg 3 and the skewed-metric run) of the N = 1 record")
+    ap.add_argument("--no-materialise", action="store_true",
+                    help="leave the returned frames in HBM (lazy PIL images) instead of copying them to host PIL images inside the timed region")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --rendezvous-only)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="entry-path check without a GPU (tests/test_dist_cpu.py): spawn / join the ranks, verify the world size, "
+                         "print the JSON line with value null, run no workload")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` started as ONE process (no WORLD_SIZE in the environment): re-execute this very command
+    line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one rank per GPU, rendezvous on 127.0.0.1),
+    so the driver's plain command and its explicit torchrun command are the same job.  Never returns when it re-executes."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-executing under torch.distributed.run\n")
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def gemm_family_profile(pipe, launches):
@@ -251,7 +275,7 @@ def roofline_blocks(prof, launch_counts, device):
 def _pmc_traffic_per_launch():
     """HBM traffic of the GEMM family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE),
     per launch like `achieved`; PMC collection cannot run inside the timed bench itself."""
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")
         try:
             with open(path) as fh:
@@ -261,10 +285,27 @@ def _pmc_traffic_per_launch():
     return None
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(unet_w, vae_w, census):
-    """Bounded CPU sample on this host (~15-25 s): two fp32 UNet forwards, one fp32 VAE decode, one LPIPS pair and 16
-    slerps of the oracle at the benchmark shapes (B=1, 64x64 latent), scaled by the transition census."""
-    from oracle import sdxl_ref as R
+    """The CPU fp32 oracle (oracle/, kind "port") on this box's host cores, bounded to ~20-30 s:
+    (1) BASELINE.md section 4's cfg-1-scale tree really RUN end to end - SDXL-Turbo 256^2, the smallest valid tree
+        (num_inference_steps 2, depth_strength 0.5, nmb_max_branches 3: 7 UNet forwards, 5 decodes, 5 frames), the engine's
+        host layer driving the oracle pipe with the benchmark's own full-size weights;
+    (2) the metric's workload (cfg 2) EXTRAPOLATED from timed samples at its shapes (UNet forward B=1 64x64 latent, VAE
+        decode, LPIPS pair, slerp) x the transition census - `value`."""
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
     cores = min(os.cpu_count() or 1, 16)     # more threads than this only slows torch's CPU GEMMs down
     torch.set_num_threads(cores)
     ucfg, vcfg = R.UNetCfg(sample_size=64), R.VAECfg()
@@ -274,9 +315,8 @@ def cpu_baseline(unet_w, vae_w, census):
     te = torch.randn(1, 1280, generator=g).half()
     ids = torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]])
     t0 = time.perf_counter()
-    for tt in (999.0, 749.0):
-        R.unet_forward(ucfg, unet_w, x, torch.tensor(tt), ctx, te, ids)
-    t_unet = (time.perf_counter() - t0) / 2
+    R.unet_forward(ucfg, unet_w, x, torch.tensor(999.0), ctx, te, ids)
+    t_unet = time.perf_counter() - t0
     t0 = time.perf_counter()
     img = R.vae_decode(vcfg, vae_w, x.float() / vcfg.scaling_factor)
     R.postprocess_u8(img)
@@ -292,11 +332,43 @@ def cpu_baseline(unet_w, vae_w, census):
     n_unet, n_vae = census.get("unet_samples") or 38.0, census.get("vae_decodes") or 17.0
     n_lp, n_sl = census.get("lpips_pairs") or 30.0, census.get("slerps") or 60.0
     t_transition = n_unet * t_unet + n_vae * t_vae + n_lp * t_lpips + n_sl * t_slerp
-    return {"value": n_vae / t_transition, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 (torch CPU, {cores} threads): 2 UNet forwards B=1 64x64 latent = {t_unet:.2f} s each, "
-                      f"1 VAE decode = {t_vae:.2f} s, 1 LPIPS pair = {t_lpips:.2f} s, 16 slerps = {t_slerp * 1e3:.2f} ms each; "
-                      f"transition = {n_unet:.0f} UNet + {n_vae:.0f} VAE + {n_lp:.0f} LPIPS + {n_sl:.0f} slerp (census) "
-                      f"= {t_transition:.1f} s extrapolated"}
+    out = {"value": n_vae / t_transition, "unit": "frames/s", "cores": cores, "kind": "port",
+           "host": {"cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": cores},
+           "sample": f"oracle fp32 (torch CPU, {cores} threads of {os.cpu_count()} on {_cpu_model()}): 1 UNet forward B=1 64x64 latent = "
+                     f"{t_unet:.2f} s, 1 VAE decode = {t_vae:.2f} s, 1 LPIPS pair = {t_lpips:.2f} s, 16 slerps = {t_slerp * 1e3:.2f} ms each; "
+                     f"transition = {n_unet:.0f} UNet + {n_vae:.0f} VAE + {n_lp:.0f} LPIPS + {n_sl:.0f} slerp (census) "
+                     f"= {t_transition:.1f} s extrapolated"}
+    # (1) the cfg-1-scale tree, really run: engine host layer on the oracle pipe
+    try:
+        import contextlib
+        import io
+        o = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=ucfg, vae_cfg=vcfg, weights=unet_w, vae_weights=vae_w)
+        set_backend(R.TorchCpuBackend())
+        with contextlib.redirect_stdout(io.StringIO()):
+            BlendingEngine.benchmark_speed, keep = (lambda self: None), BlendingEngine.benchmark_speed   # (its 512^2 probe forwards are not part of the tree)
+            try:
+                be = BlendingEngine(o, metric=lp, verbose=False)
+            finally:
+                BlendingEngine.benchmark_speed = keep
+            be.dt_vae = 0.0
+            be.set_dimensions((256, 256))
+            be.set_num_inference_steps(2)
+            be.set_branching(depth_strength=0.5, nmb_max_branches=3)
+            be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+            be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+            o.unet.calls = o.vae.calls = 0
+            t0 = time.perf_counter()
+            frames = be.run_transition(fixed_seeds=[420, 421])
+            dt = time.perf_counter() - t0
+        out["cfg1_tree"] = {"value": len(frames) / dt, "unit": "frames/s", "seconds": dt, "frames": len(frames),
+                            "unet_forwards": o.unet.calls, "vae_decodes": o.vae.calls,
+                            "workload": "SDXL-Turbo 256x256, num_inference_steps=2, depth_strength=0.5, nmb_max_branches=3 (BASELINE "
+                                        "configs[0] as its smallest valid tree), CPU fp32 oracle pipe under the engine's host layer, RUN not extrapolated"}
+    except Exception as exc:                                  # never lose the throughput line over the baseline
+        out["cfg1_tree"] = {"error": repr(exc)}
+    finally:
+        set_backend(None)
+    return out
 
 
 def skewed_metric(be, skew):
@@ -311,8 +383,63 @@ def skewed_metric(be, skew):
     return similarity
 
 
+def secondary_lines(pipe, args, branches):
+    """Two more lines for the driver's record (same process, same resident weights), each best-effort:
+    * the metric's workload under a deliberately SKEWED perceptual metric (distance x exp(3 x position)): the greedy order
+      leaves the balanced tree, the speculative frontier needs several rounds and drops speculated branches - the other end
+      of the range real LPIPS on real images will sit in (the headline's synthetic weights give a balanced tree: 1 round);
+    * BASELINE configs[2]: SDXL base 1024^2, 30 steps, guidance 4.0 (CFG), depth_strength 0.5, nmb_max_branches 15."""
+    import latentblending_amd.native as N
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.native.frames import materialise_frames
+    out = []
+
+    def timed(be, steps, warmup):
+        for _ in range(warmup):
+            be.run_transition(fixed_seeds=[420, 421])
+        be.stats.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            imgs = be.run_transition(fixed_seeds=[420, 421])
+            materialise_frames(imgs)
+        torch.cuda.synchronize()
+        return len(imgs), (time.perf_counter() - t0) / steps
+
+    try:
+        be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+        be.pair_metric = skewed_metric(be, 3.0)
+        be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+        be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+        be.set_branching(nmb_max_branches=branches)
+        n, dt = timed(be, 3, 1)
+        ev = be.stats.get("speculation_evaluated", 0) / 3
+        dr = be.stats.get("speculation_dropped", 0) / 3
+        out.append({"name": "cfg2 under a skewed metric (x exp(3 x position))", "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                    "frontier_rounds": be.stats.get("frontier_rounds", 0) / 3, "speculation_hit_rate": (ev - dr) / ev if ev else None})
+    except Exception as exc:
+        out.append({"name": "cfg2 under a skewed metric", "error": repr(exc)})
+    try:
+        base_pipe = N.NativeSDXLPipe(turbo=False, unet_native=pipe.unet_native, vae_native=pipe.vae_native, device=str(pipe.device),
+                                     allow_synthetic=True)
+        be = BlendingEngine(base_pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+        be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+        be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+        be.set_branching(depth_strength=0.5, nmb_max_branches=15)
+        n, dt = timed(be, 1, 1)
+        out.append({"name": "cfg3: SDXL base 1024x1024, 30 steps, guidance 4.0 (CFG), depth_strength 0.5, nmb_max_branches 15",
+                    "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "frames": n,
+                    "levels": [int(v) for v in be.list_idx_injection], "stems": [int(v) for v in be.list_nmb_stems]})
+        del be, base_pipe
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out.append({"name": "cfg3", "error": repr(exc)})
+    return out
+
+
 def main():
     # the host layer prints progress lines like the reference does; keep stdout for the ONE JSON line
+    respawn_under_torchrun(parse())
     real_stdout = sys.stdout
     sys.stdout = sys.stderr
     try:
@@ -328,10 +455,27 @@ def _run():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group(args.backend)
+            world = dist.get_world_size()
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+        assert world == args.gpus, f"--gpus {args.gpus} but {world} rank(s) joined the rendezvous"
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return {"metric": "transition frames/sec, SDXL-Turbo 512x512 4-step 15-branch", "value": None, "unit": "frames/s",
+                "n_gpus": world, "steps": 0, "warmup": 0, "rendezvous_only": True} if rank == 0 else None
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()               # the ranks RCCL actually sees
+    assert world == args.gpus, (f"--gpus {args.gpus} but the job has {world} rank(s): start it as `python bench.py --gpus N` "
+                                f"(re-executes itself under torch.distributed.run) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
 
     import latentblending_amd.native as N
     from latentblending_amd import BlendingEngine
@@ -391,12 +535,22 @@ def _run():
         # a farmed transition cannot be repeated by rank 0 alone (collectives), so rank 0 counts its own program
         # launches during the timed transitions (programs exist after the warm-up) and profiles them afterwards
         install_launch_counters(pipe, farm_counts)
+    from latentblending_amd.native.frames import materialise_frames
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        frames = len(be.run_transition(fixed_seeds=[420, 421]))
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+        if not args.no_materialise:          # the metric's frames are host PIL images, as the reference returns them
+            materialise_frames(imgs)
+        frames = len(imgs)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
+    if world > 1:
+        mine = torch.tensor([dt / max(args.steps, 1) * 1e3], device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(v.item()) for v in allr]
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -421,9 +575,13 @@ def _run():
                                "SDXL-Turbo 512x512, num_inference_steps=4, nmb_max_branches=%d (%d frames/transition), "
                                "fp16, fixed_seeds=[420,421], anchors not recycled" % (branches, frames),
                    "frontier_width": args.frontier, "hipgraphs": not args.no_graphs, "metric_skew": args.metric_skew,
+                   "frames_materialised_in_timed_region": not args.no_materialise,
                    "parallelism": ("branch farm over %d ranks (RCCL: one packed all-gather of branches + one of LPIPS "
                                    "scalars per round; anchors computed by every rank)" % world) if world > 1 else "single GPU",
-                   "farm": None if farm is None else {"collectives": farm.collectives, "bytes_moved": farm.bytes_moved},
+                   "farm": None if farm is None else {
+                       "collectives_per_transition": farm.collectives / max(args.steps + args.warmup, 1),
+                       "bytes_moved_per_transition": farm.bytes_moved / max(args.steps + args.warmup, 1),
+                       "ms_per_transition_by_rank": per_rank_ms},
                    "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1)},
     }
     if rank == 0 and world == 1 and not args.no_roofline:      # (needs a solo transition: no collectives)
@@ -434,6 +592,8 @@ def _run():
         torch.cuda.synchronize()
         out["roofline"], out["rooflines"] = roofline_blocks(gemm_family_profile(pipe, step_launch_counts), step_launch_counts,
                                                             f"cuda:{local_rank}")
+    if rank == 0 and world == 1 and not base and not args.no_secondary and not args.metric_skew:
+        out["secondary"] = secondary_lines(pipe, args, branches)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not base:
         out["cpu_baseline"] = cpu_baseline(unet_w, vae_w, per_transition)
     if world > 1:

@@ -48,11 +48,10 @@ int lb_slerp_batched_f16(const void* p0, const void* p1, void* out, const double
                          long npairs, long n, void* stream);
 /* the same with ELEMENT strides between consecutive pairs of each input (0 = all pairs share that tensor: the
  * parental mix of one pair of anchor latents at npairs fractions, blending_engine.py:443-450); out is
- * [npairs][n] contiguous; n % 8 == 0, n <= 32768 (L <= 90). */
+ * [npairs][n] contiguous; n % 8 == 0 (register-staged single pass up to n = 32768, two passes beyond). */
 int lb_slerp_strided_f16(const void* p0, long stride0, const void* p1, long stride1, void* out,
                          const double* fracts_dev, long npairs, long n, void* stream);
 
-void lb_slerp_set_study(int variant);   /* tools/slerp_study.py only: 1 = lerp weights, 2 = fp32 sum (NOT the reference's arithmetic) */
 
 /* latentblending/utils.py:97 interpolate_linear on tensors (blending_engine.py:650) */
 int lb_lerp_f16(const void* p0, const void* p1, void* out, long n, double fract, void* stream);
@@ -141,15 +140,11 @@ void lb_conv_halo_set_persistent(int on);
 /* Host arithmetic of a halo launch (no device work): kind 0 = not eligible, 3 = 3x3 form, 2 = 2x2 sub-pixel form; the
  * tile width (32 / 16), the number of (tile [, parity], channel block) work items and the grid that walks them. */
 void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long* items, long* grid);
-/* Timing studies only (tools/halo_study.py): bit 0 skip the epilogue, bit 1 / bit 2 halo / weight requests from the zero
- * page.  Any non-zero value makes the results wrong by construction; default 0. */
-void lb_conv_halo_set_study(int bits);
 /* "nearest-2x upsample, then 3x3 conv" (UNet / VAE upsamplers) as ONE launch of the halo-tile kernel in its 2x2 sub-pixel
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
-void lb_gemm_set_policy(int disable_mask);        /* A/B studies: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv, bit5 ENABLES the general 192x128 rule (off by default), bit6 disables the narrow 192x128 rule (short K, single partial round) */
-void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
+void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..8 as the tile offers, 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached
  *      from diffusers_holder.py:336 and :135) ------------------------------------------- */
@@ -229,6 +224,15 @@ int lb_program_instantiate(void* prog);                              /* capture 
 int lb_program_launch(void* prog, void* stream);                     /* graph launch (or eager) */
 /* eager replay with hipEvents between ops; ms_out[num_ops]; synchronises (measurement only) */
 int lb_program_time_ops(void* prog, void* stream, float* ms_out);
+
+/* ---- STUDY BUILDS ONLY (hipcc -DLB_STUDY_BUILD: `python -m latentblending_amd.csrc.build --study` -> liblbhip_study.so,
+ *      loaded with LB_HIP_LIBRARY=...).  These switches change what the kernels COMPUTE or how the tile policy decides; the
+ *      product library neither exports them nor contains the code behind them. ------------------------------------------ */
+#ifdef LB_STUDY_BUILD
+void lb_slerp_set_study(int variant);        /* tools/slerp_study.py: 1 = lerp weights, 2 = fp32 sum (NOT the reference's arithmetic) */
+void lb_conv_halo_set_study(int bits);       /* tools/halo_study.py: bit 0 skip the epilogue, bit 1 / 2 halo / weight requests from the zero page */
+void lb_gemm_set_policy(int disable_mask);   /* tools/ab_policy.py: bit0 no 256x128, bit1 no 256x256, bit2/3 no 256x256 for conv/plain, bit4 no 256x128 for conv, bit5 general 192x128 rule, bit6 no narrow 192x128 rule */
+#endif
 
 #ifdef __cplusplus
 }

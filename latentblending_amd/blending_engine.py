@@ -481,6 +481,11 @@ class BlendingEngine:
             [coeffs] * len(mine), idx_injection, steps, self.guidance_scale, [guid[k] for k in mine],
             noise_slots=(len(gaps), mine) if farm else None)
         frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
+        if farm:    # C1: rank 0's anchors (stacks + frames) become everybody's - bit-identical parents / end frames on all ranks
+            (first, last), anchor_frames = farm.share_anchor_pair([first, last], frames[:2], 0, steps, self._frame_from_u8,
+                                                                  self._latent_chw(), (self.dh.height_img, self.dh.width_img))
+            first, last = self._on_pipe_device(first), self._on_pipe_device(last)
+            frames = list(anchor_frames) + list(frames[2:])
         self._tree.reset(first, last, frames[0], frames[1])
         mid_frames = frames[2:]
         if farm:

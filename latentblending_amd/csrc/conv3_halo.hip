@@ -152,7 +152,11 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         w_off[i] = n < p.N ? (long)n * p.ldw + cl * 8 : -1;
     }
 
+#ifdef LB_STUDY_BUILD
     const int study = p.reserved_;                      // timing studies only (lb_conv_halo_set_study): 1 no epilogue, 2 halo from the zero page, 4 weights from the zero page
+#else
+    constexpr int study = 0;                            // (the study switches exist only in -DLB_STUDY_BUILD libraries)
+#endif
     auto issue_halo = [&](int j, int src_chunk, int buf) {   // one wave instruction of a halo (of the tile h_off describes)
         const lb_half* src = h_off[j] >= 0 && !(study & 2) ? p.A + h_off[j] + (long)src_chunk * 64 : zero;
         const int gidx = j * 8 + wave;
@@ -308,11 +312,13 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
 
 // 1 (default): persistent blocks with the request streams running across tile boundaries; 0: one item per block
 static int g_halo_persistent = 1;
-static int g_halo_study = 0;
 extern "C" void lb_conv_halo_set_persistent(int on) { g_halo_persistent = on; }
-// Timing studies (tools/halo_study.py): bit 0 skip the epilogue, bit 1 halo loads from the zero page, bit 2 weight
-// loads from the zero page.  Results are then WRONG by construction; 0 (default) = the real kernel.
+#ifdef LB_STUDY_BUILD
+// Timing studies (tools/halo_study.py, study builds only): bit 0 skip the epilogue, bit 1 halo loads from the zero page,
+// bit 2 weight loads from the zero page.  Results are then WRONG by construction; 0 (default) = the real kernel.
+static int g_halo_study = 0;
 extern "C" void lb_conv_halo_set_study(int bits) { g_halo_study = bits; }
+#endif
 static int halo_num_cus() {
     static int n = 0;
     if (!n) {
@@ -353,7 +359,9 @@ static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
     halo_grid(p, TW, KS, nblk, grid);
     LB_REQUIRE(nblk < (1l << 30), "halo conv: too many tiles for one launch");
     LbGemmParams pk = p;
+#ifdef LB_STUDY_BUILD
     pk.reserved_ = g_halo_study;
+#endif
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS>), dim3((unsigned)grid), dim3(512), SMEM, stream, pk);
     return lb_check_launch(KS == 2 ? "lb_upconv2x_halo_f16" : "lb_conv3x3_halo_f16");
 }

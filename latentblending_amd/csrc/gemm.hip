@@ -319,8 +319,12 @@ extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; 
 extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
 // A/B studies of the tile policy (tools/ab_policy.py): bit 0 no 256x128, bit 1 no 256x256, bit 2 no
 // 256x256 for convolutions, bit 3 no 256x256 for plain/GEGLU, bit 4 no 256x128 for convolutions
+#ifdef LB_STUDY_BUILD
 static int g_policy_off = 0;
 extern "C" void lb_gemm_set_policy(int disable_mask) { g_policy_off = disable_mask; }
+#else
+static constexpr int g_policy_off = 0;     // (the A/B switches of the tile policy exist only in -DLB_STUDY_BUILD libraries)
+#endif
 // 3x3 / stride 1 / pad 1 convs from an LDS-resident halo tile (conv3_halo.hip): 1.27-1.79x the implicit GEMM on
 // every conv of the benchmark's B=17 programs (profiles/r02_halo_bench.txt).  mode 0 = never, 1 = whenever the
 // halo grid has at least LB_HALO_MIN_BLOCKS blocks (default), 2 = whenever eligible (tests / A-B studies).

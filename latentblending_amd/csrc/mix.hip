@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict_
 // VPT 16-byte vectors of both inputs in REGISTERS between the reduction and the weighted sum: HBM is read exactly
 // once (6 B / element) without an LDS round trip, the block needs 0.5 KiB of LDS, so four 512-thread blocks share a
 // CU and one block's loads overlap another's float64 arithmetic.
-// STUDY: 0 = product; 1 = lerp weights instead of the acos / sin chain; 2 = fp32 weighted sum (NOT exact) (tools/slerp_study.py only)
+// STUDY (only instantiated with -DLB_STUDY_BUILD, tools/slerp_study.py): 0 = product; 1 = lerp weights instead of the
+// acos / sin chain; 2 = fp32 weighted sum (NOT exact)
 template <int VPT, int STUDY = 0>
 __global__ void __launch_bounds__(512) slerp_strided_kernel(const f16* __restrict__ p0, long stride0,
                                                              const f16* __restrict__ p1, long stride1,
@@ -281,13 +282,32 @@ static int slerp_batched_impl(const void* p0, const void* p1, void* out, const d
     return lb_check_launch("lb_slerp_batched_f16");
 }
 
+#ifdef LB_STUDY_BUILD
 static int g_slerp_study = 0;
 extern "C" void lb_slerp_set_study(int v) { g_slerp_study = v; }
+#endif
+
+// n > 32768 elements per pair (latents beyond 90 x 90): the pair does not fit the register-staged kernel; two passes over
+// global memory (the second one hits L2: a pair is <= a few hundred KiB), same arithmetic.
+__global__ void __launch_bounds__(512) slerp_strided_big_kernel(const f16* __restrict__ p0, long stride0,
+                                                                 const f16* __restrict__ p1, long stride1,
+                                                                 f16* __restrict__ out, const double* __restrict__ fracts,
+                                                                 long n) {
+    __shared__ double red[64];
+    const long b = blockIdx.x;
+    slerp_body<f16, 8>(p0 + b * stride0, p1 + b * stride1, out + b * n, n, fracts[b], nullptr, nullptr, false, red);
+}
 
 static int slerp_strided_impl(const void* p0, long stride0, const void* p1, long stride1, void* out,
                               const double* fracts_dev, long npairs, long n, hipStream_t stream) {
     const long nvec = n >> 3;
     const dim3 grid((unsigned)npairs), block(512);
+    if (nvec > 512 * 8) {
+        hipLaunchKernelGGL(slerp_strided_big_kernel, grid, block, 0, stream, (const f16*)p0, stride0, (const f16*)p1, stride1,
+                           (f16*)out, fracts_dev, n);
+        return lb_check_launch("lb_slerp_strided_f16(two-pass)");
+    }
+#ifdef LB_STUDY_BUILD
     if (g_slerp_study && nvec > 1024 && nvec <= 2048) {      // bottleneck studies on the L = 64 latent size only
         if (g_slerp_study == 1)
             hipLaunchKernelGGL((slerp_strided_kernel<4, 1>), grid, block, 0, stream, (const f16*)p0, stride0, (const f16*)p1, stride1,
@@ -297,6 +317,7 @@ static int slerp_strided_impl(const void* p0, long stride0, const void* p1, long
                                (f16*)out, fracts_dev, n);
         return lb_check_launch("lb_slerp_strided_f16(study)");
     }
+#endif
 #define LB_SLERP_STRIDED(V) hipLaunchKernelGGL((slerp_strided_kernel<V>), grid, block, 0, stream, (const f16*)p0, stride0, \
                                                (const f16*)p1, stride1, (f16*)out, fracts_dev, n)
     if (nvec <= 512) LB_SLERP_STRIDED(1);
@@ -309,7 +330,7 @@ static int slerp_strided_impl(const void* p0, long stride0, const void* p1, long
 
 extern "C" int lb_slerp_strided_f16(const void* p0, long stride0, const void* p1, long stride1, void* out,
                                     const double* fracts_dev, long npairs, long n, void* stream) {
-    LB_REQUIRE(npairs > 0 && n > 0 && n % 8 == 0 && n <= 512 * 8 * 8, "lb_slerp_strided_f16: n multiple of 8, <= 32768");
+    LB_REQUIRE(npairs > 0 && n > 0 && n % 8 == 0, "lb_slerp_strided_f16: n must be a positive multiple of 8");
     LB_REQUIRE(stride0 % 8 == 0 && stride1 % 8 == 0 && stride0 >= 0 && stride1 >= 0, "lb_slerp_strided_f16: strides multiples of 8");
     LB_REQUIRE(aligned16(p0) && aligned16(p1) && aligned16(out), "lb_slerp_strided_f16: 16-B alignment");
     LB_DISPATCH("lb_slerp_strided_f16", slerp_strided_impl(p0, stride0, p1, stride1, out, fracts_dev, npairs, n, s));
@@ -389,60 +410,118 @@ extern "C" int lb_lerp_f32(const void* p0, const void* p1, void* out, long n, do
 // ------------------------------------------------------------------------------------------
 #define LB_STEP_STRIDE 8
 
+// Both kernels: 16 B per lane (8 halves), blockIdx.y walks the samples so the per-sample scalars are loaded once per
+// block (no per-element division / parameter fetch); a scalar tail covers per_sample % 8 and unaligned buffers.
+
 // x_in = half(x / sqrt(sigma^2 + 1)); with `dup` the batch is written twice (CFG: [uncond | cond]).
-__global__ void scale_input_kernel(const f16* __restrict__ x, f16* __restrict__ out,
-                                   const float* __restrict__ params, long per_sample, int batch,
-                                   int dup) {
+template <bool VEC>
+__global__ void __launch_bounds__(256) scale_input_kernel(const f16* __restrict__ x, f16* __restrict__ out,
+                                                           const float* __restrict__ params, long per_sample, int batch,
+                                                           int dup) {
     const long total = per_sample * batch;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int b = (int)(i / per_sample);
+    for (int b = blockIdx.y; b < batch; b += gridDim.y) {
         const float s = params[b * LB_STEP_STRIDE + 0];
         const float denom = sqrtf(s * s + 1.0f);
-        const f16 v = (f16)((float)x[i] / denom);
-        out[i] = v;
-        if (dup) out[i + total] = v;
+        const f16* xs = x + (long)b * per_sample;
+        f16* os = out + (long)b * per_sample;
+        const long nvec = VEC ? per_sample >> 3 : 0;
+        const long stride = (long)gridDim.x * blockDim.x;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xs + i * 8);
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (f16)__fdiv_rn((float)v[j], denom);
+            *reinterpret_cast<f16x8*>(os + i * 8) = r;
+            if (dup) *reinterpret_cast<f16x8*>(os + total + i * 8) = r;
+        }
+        for (long i = (nvec << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+            const f16 v = (f16)__fdiv_rn((float)xs[i], denom);
+            os[i] = v;
+            if (dup) os[i + total] = v;
+        }
     }
+}
+
+static dim3 sample_grid(long per_sample, int batch) {
+    long gx = ((per_sample + 7) / 8 + 255) / 256;
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    return dim3((unsigned)gx, (unsigned)(batch < 32768 ? batch : 32768), 1);
 }
 
 extern "C" int lb_scale_model_input_f16(const void* x, void* out, const float* params_dev,
                                         long per_sample, int batch, int dup_for_cfg, void* stream) {
     LB_REQUIRE(per_sample > 0 && batch > 0, "lb_scale_model_input_f16: sizes");
-    LB_DISPATCH_STMT("lb_scale_model_input_f16", hipLaunchKernelGGL(scale_input_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0, s,
-                                    (const f16*)x, (f16*)out, params_dev, per_sample, batch, dup_for_cfg));
+    const bool vec = per_sample % 8 == 0 && aligned16(x) && aligned16(out);
+    LB_DISPATCH_STMT("lb_scale_model_input_f16",
+                     if (vec) hipLaunchKernelGGL(scale_input_kernel<true>, sample_grid(per_sample, batch), dim3(256), 0, s,
+                                                 (const f16*)x, (f16*)out, params_dev, per_sample, batch, dup_for_cfg);
+                     else hipLaunchKernelGGL(scale_input_kernel<false>, sample_grid(per_sample, batch), dim3(256), 0, s,
+                                             (const f16*)x, (f16*)out, params_dev, per_sample, batch, dup_for_cfg));
 }
 
 // eps layout: cfg == 0: eps[b] ; cfg == 1: eps[0..B) = uncond, eps[B..2B) = text.
 // CFG combine reproduces the fp16 tensor arithmetic of diffusers_holder.py:348-349
 // (sub, scalar mul, add — each rounded to fp16); the update itself is fp32, rounded once.
-__global__ void euler_step_kernel(const f16* __restrict__ x, const f16* __restrict__ eps,
-                                  const f16* __restrict__ noise, f16* __restrict__ out,
-                                  const float* __restrict__ params, long per_sample, int batch,
-                                  int cfg, int ancestral) {
+__device__ __forceinline__ f16 euler_one(f16 xh, f16 eu, f16 et, f16 nz, float s_from, float dt, float s_up, float g,
+                                         bool cfg, bool ancestral) {
+    f16 e = eu;
+    if (cfg) {
+        const f16 diff = (f16)((float)et - (float)eu);
+        const f16 sc = (f16)(g * (float)diff);
+        e = (f16)((float)eu + (float)sc);
+    }
+    const float xf = (float)xh;
+    const float x0 = __fsub_rn(xf, __fmul_rn(s_from, (float)e));
+    const float d = __fdiv_rn(__fsub_rn(xf, x0), s_from);
+    float nxt = __fadd_rn(xf, __fmul_rn(d, dt));
+    if (ancestral) nxt = __fadd_rn(nxt, __fmul_rn((float)nz, s_up));
+    return (f16)nxt;
+}
+
+template <bool VEC, bool CFG, bool ANC>
+__global__ void __launch_bounds__(256) euler_step_kernel(const f16* __restrict__ x, const f16* __restrict__ eps,
+                                                          const f16* __restrict__ noise, f16* __restrict__ out,
+                                                          const float* __restrict__ params, long per_sample, int batch) {
     const long total = per_sample * batch;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int b = (int)(i / per_sample);
+    for (int b = blockIdx.y; b < batch; b += gridDim.y) {
         const float s_from = params[b * LB_STEP_STRIDE + 0];
         const float dt = params[b * LB_STEP_STRIDE + 4];
         const float s_up = params[b * LB_STEP_STRIDE + 2];
         const float g = params[b * LB_STEP_STRIDE + 3];
-        f16 e;
-        if (cfg) {
-            const f16 eu = eps[i], et = eps[i + total];
-            const f16 diff = (f16)((float)et - (float)eu);
-            const f16 sc = (f16)(g * (float)diff);
-            e = (f16)((float)eu + (float)sc);
-        } else {
-            e = eps[i];
+        const long base = (long)b * per_sample;
+        const long nvec = VEC ? per_sample >> 3 : 0;
+        const long stride = (long)gridDim.x * blockDim.x;
+        const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            const long o = base + i * 8;
+            const f16x8 xv = *reinterpret_cast<const f16x8*>(x + o);
+            const f16x8 eu = *reinterpret_cast<const f16x8*>(eps + o);
+            const f16x8 et = CFG ? *reinterpret_cast<const f16x8*>(eps + total + o) : zero8;
+            const f16x8 nz = ANC ? *reinterpret_cast<const f16x8*>(noise + o) : zero8;
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = euler_one(xv[j], eu[j], et[j], nz[j], s_from, dt, s_up, g, CFG, ANC);
+            *reinterpret_cast<f16x8*>(out + o) = r;
         }
-        const float xf = (float)x[i];
-        const float x0 = __fsub_rn(xf, __fmul_rn(s_from, (float)e));
-        const float d = __fdiv_rn(__fsub_rn(xf, x0), s_from);
-        float nxt = __fadd_rn(xf, __fmul_rn(d, dt));
-        if (ancestral) nxt = __fadd_rn(nxt, __fmul_rn((float)noise[i], s_up));
-        out[i] = (f16)nxt;
+        for (long i = (nvec << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+            const long o = base + i;
+            out[o] = euler_one(x[o], eps[o], CFG ? eps[o + total] : (f16)0.f, ANC ? noise[o] : (f16)0.f, s_from, dt, s_up, g, CFG, ANC);
+        }
     }
+}
+
+template <bool VEC>
+static void euler_launch(const void* x, const void* eps, const void* noise, void* out, const float* params_dev,
+                         long per_sample, int batch, int cfg, int ancestral, hipStream_t s) {
+    const dim3 grid = sample_grid(per_sample, batch), block(256);
+#define LB_EULER(C, A) hipLaunchKernelGGL((euler_step_kernel<VEC, C, A>), grid, block, 0, s, (const f16*)x, (const f16*)eps, \
+                                          (const f16*)noise, (f16*)out, params_dev, per_sample, batch)
+    if (cfg && ancestral) LB_EULER(true, true);
+    else if (cfg) LB_EULER(true, false);
+    else if (ancestral) LB_EULER(false, true);
+    else LB_EULER(false, false);
+#undef LB_EULER
 }
 
 extern "C" int lb_euler_step_f16(const void* x, const void* eps, const void* noise, void* out,
@@ -450,7 +529,8 @@ extern "C" int lb_euler_step_f16(const void* x, const void* eps, const void* noi
                                  int ancestral, void* stream) {
     LB_REQUIRE(per_sample > 0 && batch > 0, "lb_euler_step_f16: sizes");
     LB_REQUIRE(!ancestral || noise != nullptr, "lb_euler_step_f16: ancestral step needs noise");
-    LB_DISPATCH_STMT("lb_euler_step_f16", hipLaunchKernelGGL(euler_step_kernel, dim3(ew_grid(per_sample * batch, 256)), dim3(256), 0, s,
-                                    (const f16*)x, (const f16*)eps, (const f16*)noise, (f16*)out, params_dev,
-                                    per_sample, batch, cfg, ancestral));
+    const bool vec = per_sample % 8 == 0 && aligned16(x) && aligned16(eps) && aligned16(out) && (!ancestral || aligned16(noise));
+    LB_DISPATCH_STMT("lb_euler_step_f16",
+                     if (vec) euler_launch<true>(x, eps, noise, out, params_dev, per_sample, batch, cfg, ancestral, s);
+                     else euler_launch<false>(x, eps, noise, out, params_dev, per_sample, batch, cfg, ancestral, s));
 }

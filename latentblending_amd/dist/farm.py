@@ -5,9 +5,11 @@ on MI355X) or ``gloo`` (CPU tests).  The program is SPMD: every rank runs the sa
 ``BlendingEngine`` and takes the same decisions from the same data, so no control messages exist.
 What moves:
 
-* nothing for the anchors on the native fast path: the two anchor trajectories are a B = 2 batch that
-  every rank computes itself inside the same wavefront as its share of mid branches (27 ms of
-  redundant work buys away a broadcast, an idle phase on N-2 ranks and a synchronisation point);
+* C1, native fast path: the two anchor trajectories are a B = 2 batch that every rank computes itself inside the
+  same wavefront as its share of mid branches (redundant work instead of an idle phase on N-1 ranks: the mid
+  branches need the anchors' step i-1 latents at every step), then ``share_anchor_pair`` — ONE ``broadcast`` of
+  rank 0's packed [2 x (latent stack | frame)] (1.75 MiB at 512^2) so that the STORED anchors are bit-identical
+  on every rank whatever batch width each rank computed them in;
 * C1 (generic pipes, recycled / crossfed anchors): ``share_trajectory`` — ONE ``broadcast`` of the
   [steps,4,L,L] fp16 stack from the rank that denoised it (128 KiB at 512^2);
 * C2/C3 per speculative round: ``exchange_branches`` — ONE all-gather of a packed byte slot per branch
@@ -96,6 +98,33 @@ class BranchFarm:
             stack = torch.zeros(steps, b, c, h, w, dtype=torch.float16, device=self.device)
         got = self._broadcast(stack, owner)
         return [got[i].clone() for i in range(steps)]
+
+    def share_anchor_pair(self, trajs: Sequence[Sequence[torch.Tensor]], frames: Sequence[object], owner: int, steps: int,
+                          make_frame: Callable[[torch.Tensor], object], lat_shape: Tuple[int, int, int],
+                          frame_hw: Tuple[int, int]):
+        """C1 on the native fast path: every rank has denoised both anchors itself (inside batches of different width, so
+        the last bits may differ between ranks); ONE broadcast of the owner's packed [2 x (latent stack | frame)] makes the
+        stored anchors - parents of every later branch, first / last frame of the transition - bit-identical everywhere.
+        Returns ([trajectory 1, trajectory 2], [frame 1, frame 2]); the owner keeps its own objects."""
+        c, h, w = lat_shape
+        fh, fw = frame_hw
+        lat_bytes, frm_bytes = steps * c * h * w * 2, fh * fw * 3
+        slot = (lat_bytes + frm_bytes + 15) // 16 * 16
+        buf = torch.zeros(2, slot, dtype=torch.uint8, device=self.device)
+        if self.rank == owner:
+            for k in range(2):
+                lat = torch.stack([t.reshape(c, h, w) for t in trajs[k]]).to(self.device, torch.float16).contiguous()
+                buf[k, :lat_bytes] = lat.view(torch.uint8).reshape(-1)
+                buf[k, lat_bytes:lat_bytes + frm_bytes] = self._frame_u8(frames[k]).to(self.device).reshape(-1)
+        got = self._broadcast(buf, owner)
+        if self.rank == owner:
+            return [list(trajs[0]), list(trajs[1])], [frames[0], frames[1]]
+        out_t, out_f = [], []
+        for k in range(2):
+            lat = got[k, :lat_bytes].clone().view(torch.float16).view(steps, 1, c, h, w)
+            out_t.append([lat[i] for i in range(steps)])
+            out_f.append(make_frame(got[k, lat_bytes:lat_bytes + frm_bytes].clone().view(fh, fw, 3)))
+        return out_t, out_f
 
     # -- C2/C3: one speculative round ------------------------------------------------------------
     def exchange_branches(self, mine: List[Tuple[list, object]], n_total: int, active_steps: int, total_steps: int,

@@ -60,7 +60,6 @@ SIGNATURES = {
     "lb_slerp_pairs_f64": (_i, [c_void_pp, c_void_pp, c_void_pp, C.POINTER(_d), _i, _l, _vp]),
     "lb_slerp_batched_f16": (_i, [_vp, _vp, _vp, _vp, _l, _l, _vp]),
     "lb_slerp_strided_f16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _l, _vp]),
-    "lb_slerp_set_study": (None, [_i]),
     "lb_lerp_f16": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_lerp_f32": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_scale_model_input_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
@@ -70,13 +69,11 @@ SIGNATURES = {
     "lb_gemm_set_tuning": (None, [_i, _i]),
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
-    "lb_gemm_set_policy": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_upconv2x_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_conv_halo_set_persistent": (None, [_i]),
     "lb_conv_halo_plan": (None, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
-    "lb_conv_halo_set_study": (None, [_i]),
     "lb_gemm_plan": (_i, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
     "lb_groupnorm_set_l3_chunk": (None, [_l]),
@@ -111,6 +108,13 @@ SIGNATURES = {
     "lb_program_instantiate": (_i, [_vp]),
     "lb_program_launch": (_i, [_vp, _vp]),
     "lb_program_time_ops": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
+}
+
+# exported only by study builds (-DLB_STUDY_BUILD, liblbhip_study.so): switches that change the arithmetic / the tile policy
+STUDY_SIGNATURES = {
+    "lb_slerp_set_study": (None, [_i]),
+    "lb_gemm_set_policy": (None, [_i]),
+    "lb_conv_halo_set_study": (None, [_i]),
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
@@ -151,3 +155,9 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
     setattr(api, _name, _fn if _name in _NO_CHECK else _wrap(_name, _fn))
+for _name, (_res, _args) in STUDY_SIGNATURES.items():
+    _fn = getattr(_lib, _name, None)
+    if _fn is not None:
+        _fn.restype = _res
+        _fn.argtypes = _args
+        setattr(api, _name, _fn)

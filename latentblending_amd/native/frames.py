@@ -45,3 +45,20 @@ class DeviceImage(Image.Image):
     def load(self):
         self._materialise()
         return super().load()
+
+
+def materialise_frames(frames) -> int:
+    """Bring every still device-resident ``DeviceImage`` of ``frames`` to the host in ONE device->host copy (one stream
+    synchronisation for the whole transition instead of one per frame) and build their PIL pixel cores - what the
+    reference's ``run_transition`` has done by the time it returns (blending_engine.py:347,575: real PIL images).
+    Returns the number of frames copied."""
+    todo = [f for f in frames if isinstance(f, DeviceImage) and not f._lb_loaded]
+    dev = [f for f in todo if f._lb_u8.is_cuda]
+    if dev:
+        host = torch.stack([f._lb_u8 for f in dev]).cpu().numpy()
+        for f, arr in zip(dev, host):
+            f._im = Image.fromarray(np.ascontiguousarray(arr), "RGB").im
+            f._lb_loaded = True
+    for f in todo:
+        f._materialise()
+    return len(todo)

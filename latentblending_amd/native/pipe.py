@@ -90,9 +90,9 @@ class _ImageProcessor:
         x = image.permute(0, 2, 3, 1).contiguous()
         if x.shape[-1] < 4:
             x = torch.cat([x, torch.zeros_like(x[..., :1])], dim=-1).contiguous()
+        if output_type == "np":     # diffusers' VaeImageProcessor: denormalise + clamp, float32 HWC, NOT quantised (diffusers_holder.py:141)
+            return [f.cpu().numpy() for f in (x[..., :3].float() / 2 + 0.5).clamp(0, 1)]
         u8 = ops.postprocess_u8(x.float())
-        if output_type == "np":
-            return [f.cpu().numpy().astype(np.float32) / 255.0 for f in u8]
         return [DeviceImage(f) for f in u8]
 
 
@@ -424,13 +424,14 @@ class StableDiffusionXLPipeline:
             prog.set_conditioning(ctx, pooled, ids)
             return prog
 
-        prog_a = prepared(list(anchor_conds)) if idx_injection > 0 else None
-        prog_all = prepared(list(anchor_conds) + list(mid_conds))
+        # G == 0: a farm rank that owns no mid branch of the round (fewer gaps than ranks) still runs both anchors
+        prog_a = prepared(list(anchor_conds)) if (idx_injection > 0 or G == 0) else None
+        prog_all = prepared(list(anchor_conds) + list(mid_conds)) if G else prog_a
         stream = torch.cuda.current_stream().cuda_stream
         rows_a = [sched.step_row(i, all_g[0]) for i in range(steps)]
         par_a = ops.step_params([r for r in rows_a for _ in range(A)], self.device).view(steps, A, 8)
         par_all = ops.step_params([sched.step_row(i, all_g[s]) for i in range(idx_injection, steps)
-                                   for s in range(A + G)], self.device).view(-1, A + G, 8)
+                                   for s in range(A + G)], self.device).view(-1, A + G, 8) if G else None
         shape1 = (1,) + tuple(anchor_starts[0].shape[1:])
         noise_a = noise_m = None
         if sched.ancestral:       # sample-major draws: anchor 1, anchor 2, then every mid branch
@@ -451,7 +452,7 @@ class StableDiffusionXLPipeline:
         coef_dev = torch.tensor([[float(mid_coeffs[g][i]) for g in range(G)] for i in range(steps)],
                                 dtype=torch.float64, device=self.device) if G else None
         for i in range(steps):
-            if i < idx_injection:
+            if i < idx_injection or G == 0:
                 prog, lat, params, n = prog_a, lat_a, par_a[i], A
                 noise = noise_a[i] if noise_a is not None else None
             else:
@@ -476,7 +477,7 @@ class StableDiffusionXLPipeline:
             lat_a = out[:A]
             traj_a[0].append(out[0:1])
             traj_a[1].append(out[1:2])
-            if i >= idx_injection:
+            if i >= idx_injection and G:
                 lat_m = out[A:]
                 for g in range(G):
                     traj_m[g].append(out[A + g:A + g + 1])
@@ -488,8 +489,9 @@ class StableDiffusionXLPipeline:
         prog = self.vae_program(z.shape[0], z.shape[-1])
         frames = prog.decode(z).clone()
         self.stats["vae_decodes"] += z.shape[0]
-        if output_type == "np":
-            return [f.cpu().numpy().astype(np.float32) / 255.0 for f in frames]
+        if output_type == "np":     # the reference's postprocess(..., "np"): (x / 2 + 0.5).clamp(0, 1) as float32 HWC, unquantised
+            img = (prog.image_f32[..., :3].float() / 2 + 0.5).clamp(0, 1)
+            return [f.cpu().numpy() for f in img]
         return [DeviceImage(f) for f in frames]
 
     def native_latent2image(self, latents, output_type="pil"):

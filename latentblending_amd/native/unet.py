@@ -61,10 +61,14 @@ def _pad(n: int, m: int) -> int:
 
 
 class NativeUNet:
-    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm=False):
+    def __init__(self, cfg: UNetConfig, provider, device="cuda", fuse_layernorm="auto"):
         """``fuse_layernorm``: fold the three LayerNorms of every transformer block into the GEMMs that consume them
         (LB_GEMM_LN_A: no LayerNorm launch, no normalised copy of the hidden state).
-        ``True``: row statistics accumulated inside the consumer's K loop.  OFF by default: on MI355X the 64 v_dot2 per
+        ``"auto"`` (default): per launch program - folded (``True`` form) when the program is LAUNCH-bound, i.e. at most 1024
+        tokens at the deepest level (the B = 2 anchor program at 512^2: 916 -> 706 launches, 12.40 -> 11.94 ms per forward),
+        stand-alone LayerNorms otherwise (B = 17: the fold costs 38.1 -> 42.0 ms; profiles/r03_ln_inloop_ab.txt).  Both
+        weight forms stay resident (+2.4 GB of 288 GB).
+        ``True``: row statistics accumulated inside the consumer's K loop.  Not for MFMA-bound programs: on MI355X the 64 v_dot2 per
         K-tile and wave cost the MFMA loop more than the 6 us LayerNorm launch they replace
         (profiles/r02_ln_gemm_bench.txt: QKV 57.1 + 6.4 us separate vs 70.0 us fused at B=17; GEGLU 132 + 6 vs 166).
         ``"stats"``: the GEMM that PRODUCES the hidden state (proj_in, the attention output projections, the
@@ -75,7 +79,7 @@ class NativeUNet:
         the cost is not the in-loop statistics but the consumer's epilogue, which fetches the statistics and the column
         sums row by row behind the K loop (an exposed L2 round trip per row group and block).  Both stay tested options."""
         assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
-        assert fuse_layernorm in (False, True, "stats")
+        assert fuse_layernorm in (False, True, "stats", "auto")
         self.cfg, self.device = cfg, torch.device(device)
         self.fuse_layernorm = fuse_layernorm
         self.keep_ln_weights = fuse_layernorm is not True
@@ -129,6 +133,8 @@ class NativeUNet:
         rstd * (x W'^T - mean * colsum) + b' with W' = W diag(gamma) (rounded to fp16: the MFMA operand),
         colsum[n] = sum_k W'[n][k] (of the ROUNDED values) and b' = b + W beta.  ``key`` names the packed tensors."""
         g, beta = self._norm(pv, norm_name, c, keep_host=not self.keep_ln_weights)
+        if self.fuse_layernorm is False:        # stand-alone LayerNorms only: no folded copies of the weights in HBM
+            return
         wf = (w.double() * g.double()[None, :]).to(torch.float16)
         self.w[key + ".weight"] = wf.to(self.device).contiguous()
         self.w[key + ".colsum"] = self._dev(wf.double().sum(dim=1), F32)
@@ -259,6 +265,8 @@ class UNetProgram:
     def __init__(self, net: NativeUNet, B: int, L: int):
         cfg = net.cfg
         self.net, self.B, self.L = net, B, L
+        # LayerNorm handling of THIS program ("auto": fold into the consumers only where the program is launch-bound)
+        self.ln_mode = net.fuse_layernorm if net.fuse_layernorm != "auto" else (B * max(L // 4, 1) ** 2 <= 1024)
         dev = net.device
         self.arena = Arena(dev)
         self.em = Emitter(self.arena)
@@ -342,7 +350,7 @@ class UNetProgram:
         em.groupnorm(x, n, w[p + ".norm.weight"], w[p + ".norm.bias"], B=B, HW=S, C_=c, eps=1e-6, silu=False,
                      groups=self.net.cfg.norm_groups)
         h = ar.alloc((M, c))
-        mode = self.net.fuse_layernorm
+        mode = self.ln_mode
         # "stats" mode: the producers of h leave its row statistics in `st`; a producer the planner would run split-K
         # (its final values are formed by the reduce kernel) cannot, and the LayerNorm behind it stays a launch
         st = ar.alloc((c // 32, M, 2), F32) if mode == "stats" and c % 32 == 0 else None

@@ -87,9 +87,9 @@ class _VAE:
 class _ImageProcessor:
     @staticmethod
     def postprocess(image, output_type="pil"):
+        if output_type == "np":     # diffusers VaeImageProcessor.postprocess(..., "np"): denormalised, clamped, float32 HWC - not quantised
+            return [a for a in (image.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous().numpy()]
         arr = R.postprocess_u8(image)
-        if output_type == "np":
-            return [a.astype(np.float32) / 255.0 for a in arr]
         return [Image.fromarray(a) for a in arr]
 
 

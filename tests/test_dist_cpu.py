@@ -166,3 +166,23 @@ def test_branch_farm_detects_diverging_plans(tmp_path):
     for r in (0, 1):
         msg = json.load(open(tmp_path / f"mismatch_rank{r}.json"))["msg"]
         assert "different branching plan" in msg, msg
+
+
+def test_bench_gpus_flag_spawns_the_ranks(tmp_path):
+    """The driver's plain command line `python bench.py --gpus N` must BE an N-rank job: bench.py re-executes itself under
+    torch.distributed.run when WORLD_SIZE is unset, checks that the world size equals --gpus and prints ONE JSON line from
+    rank 0.  --rendezvous-only exercises exactly that entry path on CPU (gloo, no workload); a world / --gpus mismatch must
+    fail loudly instead of silently benchmarking one GPU."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rendezvous_only"] is True
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=300, env=env1, cwd=str(tmp_path))
+    assert r.returncode != 0 and "--gpus 2 but 1 rank" in r.stderr

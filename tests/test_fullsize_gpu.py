@@ -193,6 +193,59 @@ def test_cfg2_transition_matches_oracle(full_models, results_log):
     assert d.mean() <= 2 and (d <= 4).mean() >= 0.99
 
 
+# ------------------------------------------------------------------ SDXL base: CFG, multi-level tree, full width
+def test_base_multilevel_transition_matches_oracle(full_models, results_log):
+    """BASELINE configs[2] in reduced length at FULL WIDTH (the real SDXL channel widths, 2.57 B parameters): SDXL base,
+    classifier-free guidance 4.0 (mid-damped, negative prompt = the ENCODED ""), Euler scheduler, 6 steps,
+    depth_strength 0.5, nmb_max_branches 6 -> four levels [3, 3, 4, 5] x 1 stem, i.e. parents taken from different
+    injection levels (/root/reference/latentblending/blending_engine.py:550-561).  Native engine (hipGraphs, frontier) vs
+    the same engine driving the CPU fp32 oracle pipe sequentially: identical tree, frames mean |du8| <= 2.
+    Rendered at LB_TEST_BASE_SIDE^2 (default 512: 21 CFG forwards + 6 decodes of the oracle cost ~100 s of host time;
+    1024 = the config's own size costs ~7 min; the 1024^2 kernels themselves are covered by
+    test_full_unet_and_vae_at_1024_match_oracle)."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    n, m = native(), full_models
+    _threads()
+    side = int(os.environ.get("LB_TEST_BASE_SIDE", "512"))
+    o = OP.StableDiffusionXLPipeline(turbo=False, unet_cfg=m["ucfg"], vae_cfg=m["vcfg"], weights=m["uw"], vae_weights=m["vw"])
+    p = n.NativeSDXLPipe(turbo=False, unet_native=m["unet"], vae_native=m["vae"], allow_synthetic=True)
+    np.random.seed(0)
+    set_backend(R.TorchCpuBackend())
+    be_o = BlendingEngine(o, metric=R.OracleLPIPS(7), verbose=False)
+    set_backend(None)
+    be_p = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=4)
+    for be in (be_o, be_p):
+        be.set_dimensions((side, side))
+        be.set_num_inference_steps(6)
+        be.set_guidance_scale(4.0)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=6)
+        be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+        be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+    assert [int(i) for i in be_p.list_idx_injection] == [3, 3, 4, 5] and be_p.text_embedding1[1] is not None
+    assert float(be_p.text_embedding1[1].abs().max()) > 0, "the default negative prompt \"\" is encoded, not zeroed"
+    imgs_p = be_p.run_transition(fixed_seeds=[420, 421])
+    set_backend(R.TorchCpuBackend())
+    try:
+        imgs_o = be_o.run_transition(fixed_seeds=[420, 421])
+    finally:
+        set_backend(None)
+    same_tree = be_o.tree_fracts == be_p.tree_fracts and be_o.tree_idx_injection == be_p.tree_idx_injection
+    assert len(set(be_p.tree_idx_injection)) >= 3, "the tree must be multi-level"
+    lat_err = max(rel_l2(a[-1], b[-1]) for a, b in zip(be_p.tree_latents, be_o.tree_latents)) if same_tree else float("nan")
+    d = np.stack([np.abs(np.asarray(a).astype(np.int32) - np.asarray(b).astype(np.int32)) for a, b in zip(imgs_p, imgs_o)]) \
+        if same_tree else np.zeros(1)
+    results_log["transition_base_multilevel_full_width"] = {
+        "side": side, "frames": len(imgs_p), "same_tree": bool(same_tree), "final_latent_rel_l2": lat_err,
+        "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean()), "fracts": be_p.tree_fracts,
+        "idx_injection": [int(i) for i in be_p.tree_idx_injection],
+        "sims_native": [float(s) for s in be_p.tree_similarities], "sims_oracle": [float(s) for s in be_o.tree_similarities]}
+    print(f"[parity] SDXL-base multi-level transition at full width ({side}^2, CFG 4.0, 6 steps): same_tree={same_tree} "
+          f"idx={be_p.tree_idx_injection} latent rel_l2={lat_err:.3e} mean|du8|={d.mean():.3f} within4={(d <= 4).mean():.4f}")
+    assert same_tree, (be_o.tree_fracts, be_p.tree_fracts, be_o.tree_idx_injection, be_p.tree_idx_injection)
+    assert lat_err <= 3e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99
+
+
 # ------------------------------------------------------------------ VAE precision plan on large activations
 @pytest.mark.parametrize("where", ["conv_in", "late"])
 @pytest.mark.parametrize("scaled_stream", [True, False])

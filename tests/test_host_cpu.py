@@ -267,6 +267,9 @@ def test_c_abi_exports_every_declared_symbol():
     from latentblending_amd.hip import lib
     header = open(os.path.join(ROOT, "include", "lb_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    study = re.search(r"#ifdef LB_STUDY_BUILD(.*?)#endif", header, flags=re.S)
+    header = header.replace(study.group(0), "")                     # study-build-only switches: must NOT be in the product library
+    assert set(re.findall(r"\b(lb_[a-z0-9_]+)\s*\(", study.group(1))) == set(lib.STUDY_SIGNATURES)
     declared = set(re.findall(r"\b(lb_[a-z0-9_]+)\s*\(", header))
     assert len(declared) >= 40
     cdll = ctypes.CDLL(lib.LIB_PATH)
@@ -529,11 +532,9 @@ def test_gemm_tile_policy_is_pinned():
     assert plan(512, 1280, 5120, ws=False)[1] == 1                      # no slab workspace -> never splits
     # without the zero page the direct-to-LDS family (and its 8-wave tiles) is not available
     assert plan(4352, 10240, 1280, geglu=True, zero_page=False)[0] == 1
-    lib.api.lb_gemm_set_policy(2)                                       # A/B switch: no 256x256
-    try:
-        assert plan(4352, 10240, 1280, geglu=True)[0] == 4
-    finally:
-        lib.api.lb_gemm_set_policy(0)
+    # the study switches (arithmetic / policy A/B) are NOT part of the product library
+    for name in ("lb_gemm_set_policy", "lb_slerp_set_study", "lb_conv_halo_set_study"):
+        assert not hasattr(ctypes.CDLL(lib.LIB_PATH), name), f"{name} must only exist in -DLB_STUDY_BUILD libraries"
 
 
 @pytest.mark.parametrize("TW,H,W", [(32, 16, 64), (16, 16, 16), (32, 8, 32)])

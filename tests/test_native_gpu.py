@@ -372,7 +372,7 @@ def test_branch_farm_on_rccl_world1(results_log):
         dist.destroy_process_group()
 
 
-def _farm_native_worker(rank, world, port, out_dir):
+def _farm_native_worker(rank, world, port, out_dir, frontier=None, branches=9):
     import json as _json
     import sys as _sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -390,15 +390,16 @@ def _farm_native_worker(rank, world, port, out_dir):
     pipe.scheduler.noise_source = tape
     np.random.seed(0)
     farm = BranchFarm(device=torch.device("cpu")) if world > 1 else None      # both ranks share cuda:0 -> gloo
-    be = BlendingEngine(pipe, verbose=False, frontier_width=4 * world, farm=farm, do_compile=True)
+    be = BlendingEngine(pipe, verbose=False, frontier_width=frontier or 4 * world, farm=farm, do_compile=True)
     be.set_dimensions((128, 128))
-    be.set_branching(nmb_max_branches=9)
+    be.set_branching(nmb_max_branches=branches)
     be.set_prompt1("photo of a reef")
     be.set_prompt2("rendering of an alien planet")
     tape.reset()
     imgs = be.run_transition(fixed_seeds=[420, 421])
     res = {"fracts": [float(f) for f in be.tree_fracts], "sims": [float(s) for s in be.tree_similarities],
            "frames": [int(np.asarray(i).astype(np.int64).sum()) for i in imgs], "samples": pipe.stats["unet_samples"],
+           "anchor_bits": [int(be.tree_latents[k][-1].view(torch.int16).to(torch.int64).sum()) for k in (0, -1)],
            "collectives": 0 if farm is None else farm.collectives}
     _json.dump(res, open(os.path.join(out_dir, f"native_rank{rank}_of{world}.json"), "w"))
     dist.barrier()
@@ -574,3 +575,133 @@ def test_encode_prompt_negative_semantics_match_diffusers_assembly(results_log):
     results_log["encode_prompt_4tuple_vs_transformers_assembly"] = worst
     print(f"[parity] encode_prompt 4-tuple vs transformers assembly (4 negative-prompt cases + holder default): worst rel_l2={worst:.3e}")
     assert worst <= 5e-3
+
+
+@pytest.mark.parametrize("frontier,branches", [(1, 3), (3, 5)])
+def test_branch_farm_native_rank_without_mid_branch(frontier, branches, tmp_path, results_log):
+    """Two native ranks, frontier narrower than (or not a multiple of) the world size: with frontier_width 1 the fused
+    anchor + first-round wavefront gives rank 1 NO mid branch (G = 0: anchors only), with 3 the split is 2 / 1.  Both
+    ranks must finish (no rank may die and leave the other in a collective), hold bit-identical anchors (ONE broadcast of
+    rank 0's stacks, farm.share_anchor_pair) and the tree of the one-rank run."""
+    import json
+    import socket
+    import torch.multiprocessing as mp
+
+    def port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+    mp.spawn(_farm_native_worker, args=(1, port(), str(tmp_path), frontier, branches), nprocs=1, join=True)
+    mp.spawn(_farm_native_worker, args=(2, port(), str(tmp_path), frontier, branches), nprocs=2, join=True)
+    solo = json.load(open(tmp_path / "native_rank0_of1.json"))
+    r0, r1 = [json.load(open(tmp_path / f"native_rank{r}_of2.json")) for r in (0, 1)]
+    assert r0["fracts"] == r1["fracts"] == solo["fracts"]
+    assert r0["sims"] == r1["sims"] and r0["frames"] == r1["frames"]
+    assert r0["anchor_bits"] == r1["anchor_bits"], "anchors must be bit-identical on every rank"
+    assert np.allclose(r0["sims"], solo["sims"], rtol=2e-2)
+    results_log[f"farm_native_2ranks_frontier{frontier}"] = {"samples": [r0["samples"], r1["samples"], solo["samples"]]}
+
+
+def test_branch1_crossfeed_native_matches_oracle(results_log):
+    """set_branch1_crossfeed(0.3, 0.5, 0.5) (/root/reference/latentblending/blending_engine.py:404-415): the second
+    anchor is crossfed from the first one's trajectory - sequential anchors, slerp at every crossfed step - on the native
+    pipe (sequential loop AND frontier mode) against the engine on the CPU oracle pipe."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    o, p, tape = make_pair(turbo=True)
+    runs = {}
+    for name, pipe_, backend, kw in (("oracle", o, R.TorchCpuBackend(), dict(metric=R.OracleLPIPS(7))),
+                                     ("native", p, None, {}), ("native_frontier", p, None, dict(frontier_width=4, do_compile=True))):
+        set_backend(backend)
+        np.random.seed(0)
+        be = BlendingEngine(pipe_, verbose=False, **kw)
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=5)
+        be.set_branch1_crossfeed(0.3, 0.5, 0.5)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        (o.noise if name == "oracle" else tape).reset()
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+        runs[name] = (be, [np.asarray(i).astype(np.int32) for i in imgs])
+    set_backend(None)
+    be_o, io = runs["oracle"]
+    # the crossfeed really acts: the second anchor differs from an un-crossfed run
+    np.random.seed(0)
+    be_plain = BlendingEngine(p, verbose=False)
+    be_plain.set_dimensions((128, 128)); be_plain.set_branching(nmb_max_branches=5)
+    be_plain.set_prompt1("photo of a reef"); be_plain.set_prompt2("rendering of an alien planet")
+    tape.reset()
+    be_plain.run_transition(fixed_seeds=[420, 421])
+    assert rel_l2(be_plain.tree_latents[-1][-1], runs["native"][0].tree_latents[-1][-1]) > 1e-2
+    res = {}
+    for name in ("native", "native_frontier"):
+        be_n, im = runs[name]
+        assert be_n.tree_fracts == be_o.tree_fracts and be_n.tree_idx_injection == be_o.tree_idx_injection, name
+        err = max(rel_l2(a[-1], b[-1]) for a, b in zip(be_n.tree_latents, be_o.tree_latents))
+        d = np.stack([np.abs(x - y) for x, y in zip(im, io)])
+        res[name] = {"final_latent_rel_l2": err, "mean_abs_u8": float(d.mean()), "frac_within_4": float((d <= 4).mean())}
+        assert err <= 3e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99, (name, res[name])
+    results_log["branch1_crossfeed_native"] = res
+    print(f"[parity] branch1 crossfeed (0.3, 0.5, 0.5) native vs oracle: {res}")
+
+
+def test_latent2image_np_is_the_unquantised_float_image(results_log):
+    """latent2image(output_type="np") (/root/reference/latentblending/diffusers_holder.py:141): diffusers' postprocess
+    returns the denormalised, clamped float32 HWC image - NOT u8 / 255."""
+    from latentblending_amd import DiffusersHolder
+    from latentblending_amd.backend import set_backend
+    set_backend(None)
+    o, p, _ = make_pair(turbo=True)
+    dh_o, dh_p = DiffusersHolder(o), DiffusersHolder(p)
+    z = dh_p.get_noise(7) * 0.2
+    got = dh_p.latent2image(z, output_type="np")
+    ref = dh_o.latent2image(z.cpu(), output_type="np")
+    assert got.dtype == np.float32 and got.shape == ref.shape == (128, 128, 3)
+    assert 0.0 <= float(got.min()) and float(got.max()) <= 1.0
+    assert np.abs(got * 255 - np.round(got * 255)).max() > 1e-3, "the np image must not be quantised to 1/255 steps"
+    err = float(np.abs(got - ref).mean())
+    pil = np.asarray(dh_p.latent2image(z, output_type="pil")).astype(np.float32) / 255.0
+    results_log["latent2image_np"] = {"mean_abs_err": err, "max_abs_vs_pil": float(np.abs(got - pil).max())}
+    assert err <= 2.0 / 255 and np.abs(got - pil).max() <= 0.5 / 255 + 1e-3
+    # the generic (duck-typed) route through the facade's image processor gives the same kind of array
+    img = p.vae.decode((z / p.vae.config.scaling_factor))[0]
+    gen = p.image_processor.postprocess(img, output_type="np")[0]
+    assert gen.dtype == np.float32 and np.abs(gen - got).max() <= 2e-3
+
+
+def test_wavefront_and_strided_slerp_beyond_32768_elements(results_log):
+    """A 1024^2 render has 4 x 128 x 128 = 65536 elements per latent: above what the register-staged strided slerp
+    holds.  The fused anchor + first-round wavefront (parental mix and crossfeed = strided slerps) must work there and
+    commit the sequential engine's tree; the strided kernel's two-pass path must equal the per-pair kernel bit for bit."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.hip import ops
+    set_backend(None)
+    g = torch.Generator().manual_seed(3)
+    n = 4 * 128 * 128
+    a, b = torch.randn(3, n, generator=g).half().to(DEV), torch.randn(3, n, generator=g).half().to(DEV)
+    fr = [0.25, 0.5, 0.8125]
+    got = ops.slerp_strided(a, b, torch.tensor(fr, dtype=torch.float64, device=DEV), n)
+    want = torch.stack(ops.slerp_pairs([a[i] for i in range(3)], [b[i] for i in range(3)], fr))
+    assert torch.equal(got, want)
+    bc = ops.slerp_strided(a[0].contiguous(), b[0].contiguous(), torch.tensor(fr, dtype=torch.float64, device=DEV), n,
+                           broadcast0=True, broadcast1=True)
+    assert torch.equal(bc[1], ops.slerp(a[0], b[0], 0.5))
+    _, p, tape = make_pair(turbo=True)
+
+    def run(width):
+        np.random.seed(0)
+        be = BlendingEngine(p, verbose=False, frontier_width=width)
+        be.set_dimensions((1024, 1024))
+        be.set_branching(nmb_max_branches=3)
+        be.set_prompt1("a")
+        be.set_prompt2("b")
+        tape.reset()
+        imgs = be.run_transition(fixed_seeds=[1, 2])
+        return be, imgs
+    be1, i1 = run(1)
+    be4, i4 = run(4)
+    assert be1.tree_fracts == be4.tree_fracts and len(i4) == 5 and i4[0].size == (1024, 1024)
+    d = np.stack([np.abs(np.asarray(x).astype(np.int32) - np.asarray(y).astype(np.int32)) for x, y in zip(i1, i4)])
+    results_log["wavefront_L128"] = {"mean_abs_u8": float(d.mean())}
+    assert d.mean() <= 1.0

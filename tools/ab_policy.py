@@ -6,7 +6,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import torch  # NEEDS a study build: python -m latentblending_amd.csrc.build --study; LB_HIP_LIBRARY=latentblending_amd/hip/liblbhip_study.so (LB_STUDY_BUILD)
 import latentblending_amd.native as N
 from latentblending_amd.hip import lib
 

@@ -4,7 +4,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import torch  # NEEDS a study build: python -m latentblending_amd.csrc.build --study; LB_HIP_LIBRARY=latentblending_amd/hip/liblbhip_study.so (LB_STUDY_BUILD)
 from latentblending_amd.hip import lib
 from tools.bench_round2 import graph_time
 
