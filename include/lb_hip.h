@@ -144,7 +144,9 @@ void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long*
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
-void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..8 as the tile offers, 0 = default), <0 = library default */
+void lb_gemm_set_double_step(int on);             /* tuning: 1 = small grids of 64x64 / 128x64 tiles run two K-tiles per barrier on a deep ring (same results) */
+void lb_gemm_set_prefetch(int on);                /* tuning: 1 = 6- / 8-wave GEMM tiles run an extra L2-prefetch wave (same results) */
+void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4; 16 + S = double-step form of the 64x64 / 128x64 tiles, S = 4 / 6 / 8; 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached
  *      from diffusers_holder.py:336 and :135) ------------------------------------------- */

@@ -351,6 +351,14 @@ extern "C" void lb_gemm_set_variant(int variant, int stages) {   // variant < 0:
     if (variant == 1) lb_gemm_glds_init();
 }
 
+// Tuning: 1 = small grids of 64x64 / 128x64 tiles use the double-step kernels (two K-tiles per barrier); 0 = never.
+static int g_small_double = 0;
+extern "C" void lb_gemm_set_double_step(int on) { g_small_double = on; }
+// Tuning: 0 = no prefetch wave (default until measured otherwise), > 0 = the 6- / 8-wave tiles of plain / GEGLU GEMMs get
+// an extra wave that pulls K-tile t + 5 into L2 (gemm_glds.hip).  Results are identical either way.
+void lb_gemm_glds_set_prefetch(int tiles_ahead);
+extern "C" void lb_gemm_set_prefetch(int on) { lb_gemm_glds_set_prefetch(on); }
+
 extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     // enough for the largest split the heuristic can pick (<= 16 slabs)
     return (long)16 * M * N * (long)sizeof(float);
@@ -539,8 +547,17 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
         const bool row_stat_kernels = (p.flags & LB_GEMM_ROW_STATS) || ((p.flags & LB_GEMM_LN_A) && p.row_stats != nullptr);
-        if (stages == 0 || row_stat_kernels)
+        if (stages == 0 || row_stat_kernels) {
             stages = (tile == 3 || tile == 4 || tile == 7) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
+            // small grids of 4-wave tiles (the B = 2 anchor programs): two K-tiles per barrier, deep ring (gemm_glds.hip, KD = 2)
+            const long resident = nblk * splitk;
+            const int kt_slice = ((p.K + BK - 1) / BK + splitk - 1) / splitk;
+            if (g_small_double && !row_stat_kernels && kt_slice >= 4) {
+                if (tile == 3 && resident <= 256) stages = 16 + 8;          // 128 KiB: one block per CU
+                else if (tile == 3 && resident <= 512) stages = 16 + 4;     // 64 KiB: two blocks per CU
+                else if (tile == 2 && resident <= 256) stages = 16 + 6;     // 144 KiB
+            }
+        }
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

@@ -607,10 +607,11 @@ def test_small_kernels(results_log):
 
 
 # ------------------------------------------------------------------ direct-to-LDS GEMM variant
-@pytest.mark.parametrize("stages", [2, 3, 4])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("tile,stages", [(t, s) for t in (1, 2, 3, 4, 5, 7) for s in (2, 3, 4)] +
+                         [(3, 20), (3, 22), (3, 24), (2, 20), (2, 22)])
 def test_gemm_glds_variant(tile, stages, results_log):
-    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references."""
+    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references.  stages = 16 + S: the
+    double-step form of the 4-wave tiles (two K-tiles per barrier, S-stage ring; odd K-tile counts end in a zero tile)."""
     o, l = ops(), lib()
     l.api.lb_gemm_set_variant(1, stages)
     l.api.lb_gemm_set_tuning(tile, 0)
@@ -722,3 +723,55 @@ def test_conv3x3_halo_against_conv2d(case, results_log):
     finally:
         l.api.lb_gemm_set_halo(1)
     check_close(results_log, f"halo_conv_routed_{'_'.join(map(str, case))}", got2, ref)
+
+
+@pytest.mark.parametrize("tile", [4, 5, 7])
+def test_gemm_prefetch_wave_is_bit_identical(tile, results_log):
+    """lb_gemm_set_prefetch: the extra L2-prefetch wave of the 6- / 8-wave tiles only touches cache lines - results must be
+    bit-identical to the plain kernel (plain and GEGLU, ragged M / N / K tails)."""
+    o, l = ops(), lib()
+    l.api.lb_gemm_set_tuning(tile, 0)
+    try:
+        for (M, N, K) in [(4352, 1280, 1280), (333, 132, 200), (1000, 640, 2560)]:
+            A, W = rnd(M, K, seed=171).to(DEV), rnd(N, K, seed=172, scale=K ** -0.5).to(DEV)
+            bias, res = rnd(N, seed=173, dtype=torch.float32).to(DEV), rnd(M, N, seed=174).to(DEV)
+            l.api.lb_gemm_set_prefetch(0)
+            ref = o.gemm(A, W, bias=bias, residual=res)
+            l.api.lb_gemm_set_prefetch(1)
+            got = o.gemm(A, W, bias=bias, residual=res)
+            assert torch.equal(ref, got), (tile, M, N, K)
+        if tile != 7:
+            A, W = rnd(300, 640, seed=175).to(DEV), rnd(5120, 640, seed=176, scale=640 ** -0.5).to(DEV)
+            l.api.lb_gemm_set_prefetch(0)
+            ref = o.gemm(A, W, flags=l.GEMM_GEGLU)
+            l.api.lb_gemm_set_prefetch(1)
+            assert torch.equal(ref, o.gemm(A, W, flags=l.GEMM_GEGLU))
+    finally:
+        l.api.lb_gemm_set_prefetch(0)
+        l.api.lb_gemm_set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("tile,stages", [(3, 24), (3, 20), (2, 22)])
+def test_gemm_double_step_layernorm_fold(tile, stages, results_log):
+    """The double-step kernels with the LayerNorm folded into the A operand (LB_GEMM_LN_A, in-loop statistics): the B = 2
+    anchor programs run their QKV / to_q / GEGLU projections this way."""
+    o, l = ops(), lib()
+    M, C = 512, 1280
+    x = rnd(M, C, seed=181)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=182, dtype=torch.float32), 0.1 * rnd(C, seed=183, dtype=torch.float32)
+    for geglu in (False, True):
+        N = 2560 if geglu else 1280
+        w, b = rnd(N, C, seed=184, scale=C ** -0.5), rnd(N, seed=185, dtype=torch.float32, scale=0.1)
+        y = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().t() + b
+        if geglu:
+            h, gate = y.chunk(2, dim=-1)
+            y = h * F.gelu(gate)
+        wf, colsum, b2 = o.fold_layernorm(w, b, gamma, beta)
+        l.api.lb_gemm_set_variant(1, stages)
+        l.api.lb_gemm_set_tuning(tile, 0)
+        try:
+            got = o.gemm(x.to(DEV), wf.to(DEV), bias=b2.to(DEV), flags=l.GEMM_GEGLU if geglu else 0, ln=(colsum.to(DEV), 1e-5))
+        finally:
+            l.api.lb_gemm_set_variant(-1, 0)
+            l.api.lb_gemm_set_tuning(0, 0)
+        check_close(results_log, f"double_step_ln_fold_t{tile}s{stages}_{'geglu' if geglu else 'plain'}", got, y, rel=3e-3, frac=2 ** -7)

@@ -16,6 +16,7 @@ NW = int(os.environ.get("LB_SWEEP_NW", "48"))        # distinct weight matrices 
 
 
 def timed_graph(ps, tile, splitk, stages):
+    lib.api.lb_gemm_set_halo(0)
     lib.api.lb_gemm_set_tuning(tile, splitk)
     lib.api.lb_gemm_set_variant(-1 if (tile == 0 and stages == 0) else 1, stages)
     prog = Program("sweep")
@@ -26,6 +27,7 @@ def timed_graph(ps, tile, splitk, stages):
     finally:
         lib.api.lb_gemm_set_tuning(0, 0)
         lib.api.lb_gemm_set_variant(-1, 0)
+        lib.api.lb_gemm_set_halo(1)
     prog.instantiate()
     st = torch.cuda.current_stream().cuda_stream
     prog.launch(st)
@@ -42,14 +44,20 @@ def timed_graph(ps, tile, splitk, stages):
 def main():
     shapes = [("lin", 512, 1280, 1280), ("lin", 512, 1280, 5120), ("lin", 512, 3840, 1280), ("geglu", 512, 10240, 1280),
               ("lin", 2048, 640, 640), ("lin", 2048, 640, 2560), ("lin", 2048, 1920, 640), ("geglu", 2048, 5120, 640),
-              ("lin", 8192, 320, 640), ("lin", 512, 1280, 2560)]
+              ("lin", 8192, 320, 640), ("lin", 512, 1280, 2560), ("conv", 512, 1280, 11520), ("conv", 2048, 640, 5760)]
     if len(sys.argv) > 1:
         shapes = [s for s in shapes if f"{s[1]}x{s[2]}x{s[3]}" in sys.argv[1:]]
     zp = torch.zeros(64, dtype=torch.uint8, device=DEV)
     for kind, M, N, K in shapes:
         geglu = kind == "geglu"
         nout = N // 2 if geglu else N
-        A = torch.randn(M, K, device=DEV).half()
+        conv = kind == "conv"
+        if conv:
+            cin = K // 9
+            side = 16 if M == 512 else 32
+            A = torch.randn(2, side, side, cin, device=DEV).half()
+        else:
+            A = torch.randn(M, K, device=DEV).half()
         Ws = [(torch.randn(N, K, device=DEV) * K ** -0.5).half() for _ in range(NW)]
         bias = torch.randn(N, device=DEV)
         res = torch.randn(M, nout, device=DEV).half()
@@ -66,15 +74,17 @@ def main():
                 p.partial = ws.data_ptr()
             p.flags = lib.GEMM_GEGLU if geglu else 0
             p.zero_page = zp.data_ptr()
+            if conv:
+                p.conv, p.Hin, p.Win, p.Cin, p.Hout, p.Wout, p.KH, p.KW, p.stride, p.pad, p.ups, p.ldx = 1, side, side, cin, side, side, 3, 3, 1, 1, 0, cin
             ps.append(p)
         flops = 2.0 * M * N * K
         auto, _ = timed_graph(ps, 0, 0, 0)
         row = {}
         for tile in (3, 2, 1):
-            for stages in (2, 3, 4, 6, 8):
+            for stages in (2, 3, 4, 20, 22, 24):        # 16 + S = double-step form (two K-tiles per barrier)
                 if tile == 1 and stages > 4:
                     continue
-                if tile == 2 and stages == 8:
+                if tile == 2 and stages == 24:
                     continue
                 for sk in ((1,) if geglu else (1, 2, 4)):
                     if K // 64 // sk < 2:
