@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-GEMM_OPS = ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16")      # one kernel family: MFMA GEMM / implicit-GEMM conv / halo-tile conv
+GEMM_OPS = ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16", "lb_conv3x3_narrow_f16")      # one kernel family: MFMA GEMM / implicit-GEMM conv / halo-tile conv
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
 

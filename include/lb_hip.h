@@ -134,6 +134,9 @@ int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /
  * (lb_gemm_plan reports tile code 6); lb_gemm_set_halo: 0 = never, 1 = when the halo grid fills the chip
  * (default), 2 = whenever eligible. */
 int lb_conv3x3_halo_f16(const LbGemmParams* params, void* stream);
+/* 3x3 / stride 1 / pad 1 conv with N <= 16 output channels (conv_out of the VAE decoder / UNet): weights in registers,
+ * one 16-column MFMA tile = the whole output width.  lb_gemm_f16 routes eligible convs here (lb_gemm_plan: tile code 8). */
+int lb_conv3x3_narrow_f16(const LbGemmParams* params, void* stream);
 /* Tuning: 1 (default) = persistent blocks (one per CU) whose operand request streams run across tile boundaries;
  * 0 = one (tile, channel block) item per block. */
 void lb_conv_halo_set_persistent(int on);

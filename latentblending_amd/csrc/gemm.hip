@@ -331,6 +331,8 @@ static constexpr int g_policy_off = 0;     // (the A/B switches of the tile poli
 int lb_conv3x3_halo_eligible(const LbGemmParams& p);
 long lb_conv3x3_halo_blocks(const LbGemmParams& p);
 int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream);
+int lb_conv3x3_narrow_eligible(const LbGemmParams& p);
+int lb_conv3x3_narrow_launch(LbGemmParams p, hipStream_t stream);
 int lb_upconv_halo_eligible(const LbGemmParams& p);
 int lb_upconv_halo_launch(LbGemmParams p, hipStream_t stream);
 #define LB_HALO_MIN_BLOCKS 96
@@ -494,7 +496,8 @@ extern "C" int lb_gemm_plan(const LbGemmParams* pp, int* tile, int* splitk, long
     LB_REQUIRE(pp != nullptr && pp->M > 0 && pp->N > 0 && pp->K > 0, "lb_gemm_plan: empty problem");
     int t = 0, sk = 1;
     long nb = 0;
-    if (use_halo(*pp)) { t = 6; nb = lb_conv3x3_halo_blocks(*pp); }     // tile code 6 = halo-tile conv kernel
+    if (g_halo != 0 && !g_force_tile && lb_conv3x3_narrow_eligible(*pp)) { t = 8; nb = (long)pp->M / 256; }   // tile code 8 = narrow-N conv kernel
+    else if (use_halo(*pp)) { t = 6; nb = lb_conv3x3_halo_blocks(*pp); }     // tile code 6 = halo-tile conv kernel
     else gemm_plan(*pp, t, sk, nb);
     if (tile) *tile = t;
     if (splitk) *splitk = sk;
@@ -537,6 +540,8 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(lb_upconv_halo_eligible(p) != 0, "lb_gemm_f16: scatter = 2 needs Cin % 64 == 0, W % 16 == 0, stacked [4][N][K] weights");
         LB_DISPATCH("lb_upconv2x_halo_f16", lb_upconv_halo_launch(p, s));
     }
+    if (g_halo != 0 && !g_force_tile && lb_conv3x3_narrow_eligible(p))      // N <= 16: conv_out of the VAE / UNet (conv3_narrow.hip)
+        LB_DISPATCH("lb_conv3x3_narrow_f16", lb_conv3x3_narrow_launch(p, s));
     if (use_halo(p)) LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
     int tile = 0, splitk = 1;
     long nblk = 0;

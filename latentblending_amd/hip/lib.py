@@ -73,6 +73,7 @@ SIGNATURES = {
     "lb_gemm_set_double_step": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
+    "lb_conv3x3_narrow_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_upconv2x_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_conv_halo_set_persistent": (None, [_i]),
     "lb_conv_halo_plan": (None, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)]),

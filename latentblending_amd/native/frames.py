@@ -47,6 +47,9 @@ class DeviceImage(Image.Image):
         return super().load()
 
 
+_PINNED: dict = {}
+
+
 def materialise_frames(frames) -> int:
     """Bring every still device-resident ``DeviceImage`` of ``frames`` to the host in ONE device->host copy (one stream
     synchronisation for the whole transition instead of one per frame) and build their PIL pixel cores - what the
@@ -55,7 +58,15 @@ def materialise_frames(frames) -> int:
     todo = [f for f in frames if isinstance(f, DeviceImage) and not f._lb_loaded]
     dev = [f for f in todo if f._lb_u8.is_cuda]
     if dev:
-        host = torch.stack([f._lb_u8 for f in dev]).cpu().numpy()
+        stacked = torch.stack([f._lb_u8 for f in dev])
+        key = (tuple(stacked.shape), stacked.device.index)
+        pinned = _PINNED.get(key)
+        if pinned is None:                                # one page-locked staging buffer per batch shape: DMA at PCIe speed
+            _PINNED.clear()
+            pinned = _PINNED[key] = torch.empty(stacked.shape, dtype=torch.uint8, pin_memory=True)
+        pinned.copy_(stacked, non_blocking=True)
+        torch.cuda.current_stream(stacked.device).synchronize()
+        host = pinned.numpy().copy()                      # (the PIL cores own their pixels: the staging buffer is reused)
         for f, arr in zip(dev, host):
             f._im = Image.fromarray(np.ascontiguousarray(arr), "RGB").im
             f._lb_loaded = True

@@ -522,7 +522,20 @@ def test_gemm_tile_policy_is_pinned():
     # VAE at B=17
     assert plan(4456448, 128, 1152, conv=True)[0] == 4                  # N = 128: 256x128
     assert plan(1114112, 256, 2304, conv=True)[0] == 5
-    assert plan(4456448, 4, 1152, conv=True)[0] == 3                    # conv_out: 3 real columns
+    assert plan(4456448, 4, 1152, conv=True)[0] == 3                    # conv_out: 3 real columns (this bare plan describes no 3x3 geometry)
+
+    def conv_plan(B, H, Cin, N, flags=0):
+        p = lib.LbGemmParams()
+        p.M, p.N, p.K, p.conv, p.flags = B * H * H, N, 9 * Cin, 1, flags
+        p.Hin = p.Win = p.Hout = p.Wout = H
+        p.Cin, p.KH, p.KW, p.stride, p.pad, p.ldx = Cin, 3, 3, 1, 1, Cin
+        p.zero_page = 64
+        t, sk, nb = ctypes.c_int(), ctypes.c_int(), ctypes.c_long()
+        lib.api.lb_gemm_plan(ctypes.byref(p), ctypes.byref(t), ctypes.byref(sk), ctypes.byref(nb))
+        return t.value, nb.value
+    assert conv_plan(17, 512, 128, 4, lib.GEMM_OUT_F32) == (8, 17 * 1024)   # VAE conv_out: narrow-N kernel, 16x16-pixel tiles
+    assert conv_plan(17, 64, 320, 4) == (8, 17 * 16)                        # UNet conv_out
+    assert conv_plan(17, 64, 320, 320)[0] == 6                              # ordinary widths: halo-tile kernel
     # UNet at B=2 (M = 512 / 2048): small tiles, split-K where K is long
     assert plan(512, 1280, 1280) == (3, 1, 160)
     assert plan(512, 1280, 5120) == (3, 4, 160)

@@ -775,3 +775,34 @@ def test_gemm_double_step_layernorm_fold(tile, stages, results_log):
             l.api.lb_gemm_set_variant(-1, 0)
             l.api.lb_gemm_set_tuning(0, 0)
         check_close(results_log, f"double_step_ln_fold_t{tile}s{stages}_{'geglu' if geglu else 'plain'}", got, y, rel=3e-3, frac=2 ** -7)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 128, 3, True), (1, 64, 320, 4, False), (3, 16, 64, 7, True)])
+def test_conv3x3_narrow_output(case, results_log):
+    """conv3_narrow.hip: the conv_out layers (VAE 128 -> 3 with fp32 output, UNet 320 -> 4 fp16) against F.conv2d; the
+    launcher must route them there by itself (lb_gemm_plan tile code 8)."""
+    import ctypes as C
+    o, l = ops(), lib()
+    B, H, Cin, Cout, f32 = case
+    x = rnd(B, Cin, H, H, seed=201)
+    w = rnd(Cout, Cin, 3, 3, seed=202, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=203, dtype=torch.float32)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1)
+    cout_p = (Cout + 3) // 4 * 4
+    wp = torch.zeros(cout_p, 9 * Cin, dtype=torch.float16)
+    wp[:Cout] = o.pack_conv_weight(w, Cin)
+    bp = torch.zeros(cout_p, dtype=torch.float32)
+    bp[:Cout] = b
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    p = l.LbGemmParams()
+    p.M, p.N, p.K, p.conv, p.flags = B * H * H, cout_p, 9 * Cin, 1, (l.GEMM_OUT_F32 if f32 else 0)
+    p.Hin = p.Win = p.Hout = p.Wout = H
+    p.Cin, p.KH, p.KW, p.stride, p.pad, p.ldx = Cin, 3, 3, 1, 1, Cin
+    p.zero_page = o.zero_page(DEV).data_ptr()
+    t = C.c_int()
+    l.api.lb_gemm_plan(C.byref(p), C.byref(t), None, None)
+    assert t.value == 8
+    got = o.gemm(xn, wp.to(DEV), bias=bp.to(DEV), flags=l.GEMM_OUT_F32 if f32 else 0, conv=dict(KH=3, KW=3, stride=1, pad=1))
+    assert got.dtype == (torch.float32 if f32 else torch.float16)
+    check_close(results_log, f"conv3x3_narrow_{'_'.join(map(str, case))}", got[..., :Cout], ref)
+    assert float(got[..., Cout:].abs().max()) == 0 if cout_p > Cout else True

@@ -17,7 +17,7 @@ def table(prog, glog, alog, title, fh):
     rows, gi, ai = [], 0, 0
     by_kind = defaultdict(float)
     for n, t in zip(names, ms):
-        if n in ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16"):
+        if n in ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16", "lb_conv3x3_narrow_f16"):
             g = glog[gi]; gi += 1
             halo = n != "lb_gemm_f16"
             rows.append((t, f"gemm{'(halo conv)' if halo else '(conv)' if g['conv'] else ''} M={g['M']} N={g['N']} K={g['K']}", g["flops"]))
@@ -53,7 +53,7 @@ def main():
             ctx = torch.randn(B, 77, 2048, device="cuda").half()
             up.set_conditioning(ctx, torch.randn(B, 1280, device="cuda").half(), torch.tensor([[512.0, 512, 0, 0, 512, 512]] * B, device="cuda"))
             up.forward(torch.randn(B, 4, 64, 64, device="cuda").half(), torch.full((B,), 499.0))
-            nc = sum(1 for n in up.prog_cond.op_names() if n in ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16"))
+            nc = sum(1 for n in up.prog_cond.op_names() if n in ("lb_gemm_f16", "lb_conv3x3_halo_f16", "lb_upconv2x_halo_f16", "lb_conv3x3_narrow_f16"))
             table(up.prog_step, up.em.gemm_log[nc:], up.em.attn_log, f"UNet step program B={B} L=64", fh)
             table(up.prog_cond, up.em.gemm_log[:nc], [], f"UNet conditioning program B={B}", fh)
             up.enable_graphs()
