@@ -78,10 +78,6 @@ enum {
     LB_GEMM_RELU = 32,       /* ReLU after bias/residual */
     LB_GEMM_QUICK_GELU = 128,/* x * sigmoid(1.702 x) after bias (CLIP-L MLP) */
     LB_GEMM_GELU = 256,      /* erf GELU after bias (OpenCLIP bigG MLP) */
-    LB_GEMM_ROW_STATS = 512, /* also write, per output row and 32-column slot, (sum, sum of squares) of the STORED fp16
-                              * values to row_stats[slot][M] (float2): the LayerNorm statistics of this GEMM's output,
-                              * for a consumer that runs LB_GEMM_LN_A with row_stats set.  Plain fp16-out GEMM of the
-                              * direct-to-LDS family, N % 32 == 0, never split-K */
     LB_GEMM_LN_A = 64        /* A is consumed through a LayerNorm over its K columns (K = the normalised width):
                                 C = LN(A) . Wt computed as rstd_m * (A . W'^T - mean_m * colsum) + bias with
                                 W' = W * gamma (folded by the caller), ln_colsum[n] = sum_k W'[n][k],
@@ -119,9 +115,8 @@ typedef struct LbGemmParams {
                                              * (parity py*2+px), halo-tile kernel only (lb_upconv2x_halo_f16) */
     const float* ln_colsum;  /* LB_GEMM_LN_A: [N] fp32 column sums of W' */
     float ln_eps;            /* LB_GEMM_LN_A: LayerNorm epsilon */
-    int ln_nslots;           /* LB_GEMM_LN_A with row_stats: number of 32-column slots of A's producer (= K / 32) */
-    float* row_stats;        /* LB_GEMM_ROW_STATS: output [N/32][M] float2;  LB_GEMM_LN_A: if non-null, INPUT statistics
-                              * of A's rows left by the producing GEMM (else they are accumulated inside the K loop) */
+    int reserved2_;
+    void* reserved3_;
 } LbGemmParams;
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
@@ -147,9 +142,7 @@ void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long*
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
-void lb_gemm_set_double_step(int on);             /* tuning: 1 = small grids of 64x64 / 128x64 tiles run two K-tiles per barrier on a deep ring (same results) */
-void lb_gemm_set_prefetch(int on);                /* tuning: 1 = 6- / 8-wave GEMM tiles run an extra L2-prefetch wave (same results) */
-void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4; 16 + S = double-step form of the 64x64 / 128x64 tiles, S = 4 / 6 / 8; 0 = default), <0 = library default */
+void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached
  *      from diffusers_holder.py:336 and :135) ------------------------------------------- */

@@ -353,14 +353,6 @@ extern "C" void lb_gemm_set_variant(int variant, int stages) {   // variant < 0:
     if (variant == 1) lb_gemm_glds_init();
 }
 
-// Tuning: 1 = small grids of 64x64 / 128x64 tiles use the double-step kernels (two K-tiles per barrier); 0 = never.
-static int g_small_double = 0;
-extern "C" void lb_gemm_set_double_step(int on) { g_small_double = on; }
-// Tuning: 0 = no prefetch wave (default until measured otherwise), > 0 = the 6- / 8-wave tiles of plain / GEGLU GEMMs get
-// an extra wave that pulls K-tile t + 5 into L2 (gemm_glds.hip).  Results are identical either way.
-void lb_gemm_glds_set_prefetch(int tiles_ahead);
-extern "C" void lb_gemm_set_prefetch(int on) { lb_gemm_glds_set_prefetch(on); }
-
 extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     // enough for the largest split the heuristic can pick (<= 16 slabs)
     return (long)16 * M * N * (long)sizeof(float);
@@ -472,8 +464,8 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
     const int bn = tile == 5 ? 256 : ((tile == 1 || tile == 4 || tile == 7) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
-    // (LN_A: a block must see whole rows of A; ROW_STATS: the statistics are taken where the final values are formed)
-    if (!geglu && p.partial != nullptr && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_ROW_STATS))) {
+    // (LN_A: a block must see whole rows of A)
+    if (!geglu && p.partial != nullptr && !(p.flags & LB_GEMM_LN_A)) {
         const int k_tiles = (p.K + BK - 1) / BK;
         if (g_force_splitk) splitk = g_force_splitk;
         else if (nblk <= 256) {
@@ -528,13 +520,6 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
                    "lb_gemm_f16: LB_GEMM_LN_A needs a plain / GEGLU GEMM of the direct-to-LDS family with ln_colsum");
         LB_REQUIRE(p.lda >= p.K && !(p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: LB_GEMM_LN_A normalises whole rows of A");
     }
-    if (p.flags & LB_GEMM_ROW_STATS) {
-        LB_REQUIRE(!p.conv && p.row_stats != nullptr && p.zero_page != nullptr && g_variant == 1 && p.N % 32 == 0 &&
-                       !(p.flags & (LB_GEMM_GEGLU | LB_GEMM_TRANS_OUT | LB_GEMM_OUT_F32 | LB_GEMM_LN_A)),
-                   "lb_gemm_f16: LB_GEMM_ROW_STATS needs a plain fp16-out GEMM of the direct-to-LDS family, N % 32 == 0, row_stats");
-    }
-    if ((p.flags & LB_GEMM_LN_A) && p.row_stats != nullptr)
-        LB_REQUIRE(p.ln_nslots > 0 && p.ln_nslots * 32 == p.K, "lb_gemm_f16: LB_GEMM_LN_A with row_stats needs ln_nslots = K / 32");
     if (p.alpha == 0.f) p.alpha = 1.f;
     if (p.scatter == 2) {       // all four sub-pixel parities in one launch: only the halo kernel implements it
         LB_REQUIRE(lb_upconv_halo_eligible(p) != 0, "lb_gemm_f16: scatter = 2 needs Cin % 64 == 0, W % 16 == 0, stacked [4][N][K] weights");
@@ -551,18 +536,8 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     int stages = g_stages;
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
-        const bool row_stat_kernels = (p.flags & LB_GEMM_ROW_STATS) || ((p.flags & LB_GEMM_LN_A) && p.row_stats != nullptr);
-        if (stages == 0 || row_stat_kernels) {
+        if (stages == 0)
             stages = (tile == 3 || tile == 4 || tile == 7) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
-            // small grids of 4-wave tiles (the B = 2 anchor programs): two K-tiles per barrier, deep ring (gemm_glds.hip, KD = 2)
-            const long resident = nblk * splitk;
-            const int kt_slice = ((p.K + BK - 1) / BK + splitk - 1) / splitk;
-            if (g_small_double && !row_stat_kernels && kt_slice >= 4) {
-                if (tile == 3 && resident <= 256) stages = 16 + 8;          // 128 KiB: one block per CU
-                else if (tile == 3 && resident <= 512) stages = 16 + 4;     // 64 KiB: two blocks per CU
-                else if (tile == 2 && resident <= 256) stages = 16 + 6;     // 144 KiB
-            }
-        }
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

@@ -56,25 +56,13 @@ __device__ __forceinline__ void ln_accumulate(const f16x8 (&af)[TM], float (&sum
 // 170 tiles of 256x128 (2/3 of the chip, one round) but 230 tiles of 192x128 at 3/4 of the work each.  Its weight
 // tile (128 rows) is not a multiple of the 48 rows one round of its 384 threads stages: the third round is half
 // masked (rows >= BN fetch the zero page into 16 padding rows of the stage).
-// LNA: 0 none; 1 LayerNorm of A folded in, row statistics accumulated from the A fragments inside the K loop; 2 folded
-// in with the statistics read from p.row_stats (left there by the epilogue of the GEMM that produced A, STATS).
-// STATS: this GEMM's epilogue writes the row statistics of its output (LB_GEMM_ROW_STATS).
-// PF > 0: one EXTRA wave per block (threads NT .. NT+63) is an L2 prefetcher: while the compute waves multiply K-tile t it
-// touches one byte of every 128-B line of K-tile t + PF (BM rows of A, BN rows of W), never waits for the data and takes
-// part in the per-tile barrier only.  The compute waves' direct-to-LDS requests of that tile (issued S-1 tiles ahead) then
-// hit the XCD's L2 instead of paying Infinity-Cache / HBM latency with only S-1 tiles (96 KiB) in flight per CU: the ring
-// depth no longer has to cover the memory latency, only the L2 latency.  (A prefetch issued by the compute waves
-// themselves would not do: vmcnt retires in order, so a slow prefetch would hold back the wait for the tile behind it.)
-// KD = 2 ("double step", 4-wave tiles on small grids): TWO K-tiles per barrier.  A 64x64 tile gives a wave only 8 MFMAs
-// (128 cycles of matrix work) per K-tile against ~700 cycles of fixed cost per barrier episode (counted wait + barrier,
-// the LDS round trip of the fragment reads, the request issue): the B = 2 anchor programs' GEMMs ran at 0.4 us per
-// K-tile whatever the ring depth (profiles/r03_small_m_sweep.txt).  Here one episode waits for tiles t and t+1, reads all
-// their fragments in one burst (one exposed LDS latency) and issues 2 x 16 MFMAs; the ring holds S (even) tiles, S-2 in
-// flight.  K-tiles past the end of an odd-length K range are zero tiles (masked requests), as in the prologue.
-template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, int LNA = 0, bool STATS = false, int PF = 0, int KD = 1>
-__global__ void __launch_bounds__(WMW * 128 + (PF ? 64 : 0)) gemm_f16_glds_kernel(const LbGemmParams p) {
-    static_assert(KD == 1 || (KD == 2 && S % 2 == 0 && S >= 4 && PF == 0), "double-step form: even ring of >= 4 stages");
-    constexpr int NT = WMW * 128;           // COMPUTE threads per block
+// LNA: 0 none; 1 LayerNorm of A folded in, row statistics accumulated from the A fragments inside the K loop (used by the
+// launch-bound B = 2 programs).  (A second form - statistics written by the PRODUCING GEMM's epilogue and only applied here -
+// was built in round 2, measured slower than the stand-alone LayerNorm at every batch size and removed in round 3:
+// profiles/r02_ln_stats_ab.txt, git history.)
+template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, int LNA = 0>
+__global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmParams p) {
+    constexpr int NT = WMW * 128;           // threads per block
     constexpr int RPI = NT / 8;             // tile rows covered by one round of wave instructions
     constexpr int AI = BM * 8 / NT;         // wave instructions (16-B chunks per thread) of A per K-tile
     constexpr int WI = (BN * 8 + NT - 1) / NT;
@@ -113,56 +101,6 @@ __global__ void __launch_bounds__(WMW * 128 + (PF ? 64 : 0)) gemm_f16_glds_kerne
     const int nkt = kt_end - kt_begin;
     const int k_end = kt_end * BK < p.K ? kt_end * BK : p.K;
 
-    if constexpr (PF > 0) {
-        if (wave == WMW * 2) {              // ---- the prefetch wave ----
-            constexpr int NPL = (BM + BN + 63) / 64;
-            const lb_half* rowp[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int r = lane + 64 * j;
-                const lb_half* ptr = nullptr;
-                if (r < BM) {
-                    const int m = m0 + r;
-                    if (!CONV && m < p.M) ptr = p.A + (long)m * p.lda;
-                } else if (r < BM + BN) {
-                    const int tr = r - BM;
-                    int n;
-                    bool ok;
-                    if (GEGLU) {
-                        const int sub = tr >> 4;
-                        const int nn = n0 + (sub >> 1) * 16 + (tr & 15);
-                        n = (sub & 1) * (p.N / 2) + nn;
-                        ok = nn < p.N / 2;
-                    } else {
-                        n = n0 + tr;
-                        ok = n < p.N;
-                    }
-                    if (ok) ptr = p.W + (long)n * p.ldw;
-                }
-                rowp[j] = ptr;
-            }
-            unsigned sink = 0;              // the loads' common destination: kept live (and in one register) to the end
-            // tiles S-1 .. PF-1 are requested by the compute waves during their first iterations: warm them right away
-            // (tiles 0 .. S-2 are in the compute waves' prologue burst already)
-            for (int k0 = (kt_begin + S - 1) * BK; k0 < (kt_begin + PF) * BK && k0 < k_end; k0 += BK) {
-#pragma unroll
-                for (int j = 0; j < NPL; ++j)
-                    if (rowp[j]) asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(rowp[j] + k0) : "memory");
-            }
-            int k = (kt_begin + PF) * BK;
-            for (int t = 0; t < nkt; ++t) {
-                if (k < k_end) {
-#pragma unroll
-                    for (int j = 0; j < NPL; ++j)
-                        if (rowp[j]) asm volatile("global_load_ubyte %0, %1, off" : "+v"(sink) : "v"(rowp[j] + k) : "memory");
-                }
-                k += BK;
-                __builtin_amdgcn_s_barrier();   // (one barrier per K-tile, like the compute waves)
-            }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink)::"memory");
-            return;
-        }
-    }
     // thread (r = tid>>3 (+32 i), s = tid&7) owns physical chunk s of tile row r and fetches logical
     // chunk s ^ (r & 7); (r & 7) == (lane >> 3) for every i because row groups start at multiples of 8
     const int row0 = tid >> 3;
@@ -300,33 +238,6 @@ __global__ void __launch_bounds__(WMW * 128 + (PF ? 64 : 0)) gemm_f16_glds_kerne
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     };
 
-    if constexpr (KD == 2) {
-        // ---- double-step form: prologue tiles 0 .. S-3, then per episode tiles (t, t+1) ----
-#pragma unroll
-        for (int s = 0; s < S - 2; ++s) issue_tile(s);
-        int st = 0;
-        for (int t = 0; t < nkt; t += 2) {
-            wait_vm_barrier<(S - 4) * NL>();  // tiles t, t+1 landed everywhere; the stages of tiles t-2, t-1 are free
-            int r0 = st - 2, r1 = st - 1;
-            if (r0 < 0) { r0 += S; r1 += S; }
-            issue_tile(r0);                   // tiles t+S-2, t+S-1 (zero tiles past the end)
-            issue_tile(r1);
-            f16x8 a0[TM], w0[TN], a1[TM], w1[TN], a2[TM], w2[TN], a3[TM], w3[TN];
-            read_frags(st, 0, a0, w0);
-            read_frags(st, 1, a1, w1);
-            read_frags(st + 1, 0, a2, w2);
-            read_frags(st + 1, 1, a3, w3);
-            if (LNA == 1) {
-                ln_accumulate<TM>(a0, ln_sum, ln_sq); ln_accumulate<TM>(a1, ln_sum, ln_sq);
-                ln_accumulate<TM>(a2, ln_sum, ln_sq); ln_accumulate<TM>(a3, ln_sum, ln_sq);
-            }
-            mma_rows(a0, w0, 0, TM);
-            mma_rows(a1, w1, 0, TM);
-            mma_rows(a2, w2, 0, TM);
-            mma_rows(a3, w3, 0, TM);
-            st = st + 2 == S ? 0 : st + 2;
-        }
-    } else {
     // ---- prologue: tiles 0 .. S-2 in flight ----
 #pragma unroll
     for (int s = 0; s < S - 1; ++s) issue_tile(s);
@@ -388,7 +299,6 @@ __global__ void __launch_bounds__(WMW * 128 + (PF ? 64 : 0)) gemm_f16_glds_kerne
         }
         st = st + 1 == S ? 0 : st + 1;
     }
-    }   // KD
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before exit/epilogue
 
     // ---- epilogue (identical to gemm.hip) ----
@@ -412,20 +322,7 @@ __global__ void __launch_bounds__(WMW * 128 + (PF ? 64 : 0)) gemm_f16_glds_kerne
         const float inv_k = 1.f / (float)p.K;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float su, sq;
-            if (LNA == 1) {
-                su = ln_sum[i];
-                sq = ln_sq[i];
-            } else {        // the producer's 32-column slots of this row, four interleaved subsets (one per g), fixed order
-                const int m = m0 + wave_m * WROWS + i * 16 + l16;
-                const float2* st = reinterpret_cast<const float2*>(p.row_stats) + (m < p.M ? m : p.M - 1);
-                su = sq = 0.f;
-                for (int sl = g; sl < p.ln_nslots; sl += 4) {
-                    const float2 v = st[(long)sl * p.M];
-                    su += v.x;
-                    sq += v.y;
-                }
-            }
+            float su = ln_sum[i], sq = ln_sq[i];
             su += __shfl_xor(su, 16, LB_WAVE); sq += __shfl_xor(sq, 16, LB_WAVE);
             su += __shfl_xor(su, 32, LB_WAVE); sq += __shfl_xor(sq, 32, LB_WAVE);
             const float mean = su * inv_k;
@@ -439,11 +336,6 @@ __global__ void __launch_bounds__(WMW * 128 + (PF ? 64 : 0)) gemm_f16_glds_kerne
                                                            n0 + wave_n * (BN / 64) * 16 + 4 * g, &ln);
         return;
     }
-    if (STATS) {
-        lb_gemm_tile_epilogue_stats<TM, TN>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
-                                            n0 + wave_n * (BN / 64) * 16 + 4 * g);
-        return;
-    }
     lb_gemm_tile_epilogue<TM, TN, GEGLU>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
                                          n0 + wave_n * (BN / 64) * 16 + 4 * g);
 }
@@ -454,50 +346,12 @@ constexpr int glds_stage_rows() {                       // A rows + weight rows 
     return BM + WI * RPI;
 }
 
-// EXTRA: the row-statistics kernels (LNA = 2 consumers, STATS producers) exist for this (tile, stages) pair - only the
-// default stage count of every tile, to keep the number of instantiations down; lb_gemm_f16 picks that stage count
-// whenever a launch asks for them.
-static int g_glds_prefetch = 0;            // K-tiles ahead the prefetch wave runs (0 = no prefetch wave); lb_gemm_set_prefetch
-void lb_gemm_glds_set_prefetch(int tiles_ahead) { g_glds_prefetch = tiles_ahead; }
-#define LB_PF_AHEAD 5
-
-template <int BM, int BN, int S, int WMW = 2, bool EXTRA = false>
+template <int BM, int BN, int S, int WMW = 2>
 static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t smem = (size_t)S * glds_stage_rows<BM, BN, WMW>() * BK * sizeof(f16);
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
     const dim3 block(WMW * 128);
     const bool lna = (p.flags & LB_GEMM_LN_A) != 0;
-    if constexpr (WMW >= 3) {               // prefetch-wave form: plain / GEGLU contractions on the 6- and 8-wave tiles
-        if (g_glds_prefetch > 0 && !p.conv && !lna && !(p.flags & LB_GEMM_ROW_STATS) && p.splitk <= 1) {
-            static bool allowed = false;
-            if (!allowed) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, false, LB_PF_AHEAD>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 0, false, LB_PF_AHEAD>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                allowed = true;
-            }
-            const dim3 blockp(WMW * 128 + 64);
-            if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 0, false, LB_PF_AHEAD>), grid, blockp, smem, stream, p);
-            else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, false, LB_PF_AHEAD>), grid, blockp, smem, stream, p);
-            return 0;
-        }
-    }
-    const bool from_stats = lna && p.row_stats != nullptr;
-    const bool stats = (p.flags & LB_GEMM_ROW_STATS) != 0;
-    if constexpr (EXTRA) {
-        if (stats) {
-            hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, true>), grid, block, smem, stream, p);
-            return 0;
-        }
-        if (from_stats) {
-            if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 2>), grid, block, smem, stream, p);
-            else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 2>), grid, block, smem, stream, p);
-            return 0;
-        }
-    } else if (stats || from_stats) {
-        LB_REQUIRE(false, "lb_gemm_f16: row-statistics kernels exist for the default stage count of a tile only");
-    }
     if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>), grid, block, smem, stream, p);
     else if (geglu && lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 1>), grid, block, smem, stream, p);
     else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW>), grid, block, smem, stream, p);
@@ -506,42 +360,8 @@ static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t str
     return 0;
 }
 
-// double-step variants (KD = 2): 64x64 with 8 / 4 stages, 128x64 with 6 / 4 stages
-template <int BM, int BN, int S>
-static int launch_glds_double(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
-    constexpr size_t smem = (size_t)S * glds_stage_rows<BM, BN, 2>() * BK * sizeof(f16);
-    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0, lna = (p.flags & LB_GEMM_LN_A) != 0;
-    static bool allowed = false;
-    if (!allowed) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S, 2, 0, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, 2, 0, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, 2, 0, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, 2, 1, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, 2, 1, false, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        allowed = true;
-    }
-    const dim3 block(256);
-    if (p.conv) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, true, false, S, 2, 0, false, 0, 2>), grid, block, smem, stream, p);
-    else if (geglu && lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, 2, 1, false, 0, 2>), grid, block, smem, stream, p);
-    else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, 2, 0, false, 0, 2>), grid, block, smem, stream, p);
-    else if (lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, 2, 1, false, 0, 2>), grid, block, smem, stream, p);
-    else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, 2, 0, false, 0, 2>), grid, block, smem, stream, p);
-    return 0;
-}
-
-// stages >= 16 selects the double-step form: 16 + S (S = 4, 6, 8)
-int lb_gemm_launch_glds_double(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
-    if (tile == 3) {
-        if (stages >= 8) return launch_glds_double<64, 64, 8>(p, grid, stream);
-        if (stages >= 6) return launch_glds_double<64, 64, 6>(p, grid, stream);
-        return launch_glds_double<64, 64, 4>(p, grid, stream);
-    }
-    if (stages >= 6) return launch_glds_double<128, 64, 6>(p, grid, stream);
-    return launch_glds_double<128, 64, 4>(p, grid, stream);
-}
-
 // dynamic LDS above 64 KiB needs an opt-in per kernel; done once, outside of any stream capture
-template <int BM, int BN, int S, int WMW = 2, bool EXTRA = false>
+template <int BM, int BN, int S, int WMW = 2>
 static void allow_lds() {
     const int smem = S * glds_stage_rows<BM, BN, WMW>() * BK * (int)sizeof(f16);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, true, false, S, WMW>),
@@ -554,53 +374,46 @@ static void allow_lds() {
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if constexpr (EXTRA) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    }
 }
 
 void lb_gemm_glds_init() {
     static bool done = false;
     if (done) return;
     done = true;
-    allow_lds<128, 128, 2, 2, true>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
-    allow_lds<128, 64, 2, 2, true>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
-    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2, true>(); allow_lds<64, 64, 4>();
-    allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4, true>();
-    allow_lds<256, 256, 2, 4, true>();
-    allow_lds<192, 128, 3, 3, true>();
+    allow_lds<128, 128, 2, 2>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
+    allow_lds<128, 64, 2, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
+    allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2>(); allow_lds<64, 64, 4>();
+    allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4>();
+    allow_lds<256, 256, 2, 4>();
+    allow_lds<192, 128, 3, 3>();
 }
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave),
-// 7 = 192x128 (6 waves, 3-stage ring); stages: 2..4 (0 = default for the tile); 16 + S = the double-step form of the
-// 64x64 / 128x64 tiles with an S-stage ring (S = 4, 6, 8).  (Deeper single-step rings, S = 6 / 8, were measured and bought
-// nothing: profiles/r03_small_m_sweep.txt - the small tiles are bound by the per-barrier episode, not by memory latency.)
+// 7 = 192x128 (6 waves, 3-stage ring); stages: 2..4 (0 = default for the tile).
+// Round-3 experiments that were built, verified and measured, and are NOT in this file (git history: commits 1e5bf26 ..
+// "Narrow-N conv kernel"; records in profiles/): deeper single-step rings (S = 6 / 8) and a double-step form (two K-tiles
+// per barrier) for the 64x64 / 128x64 tiles - no gain at any depth (profiles/r03_small_m_sweep*.txt: the B = 2 GEMMs
+// stay at ~10 us whatever the loop structure); an extra L2-prefetch WAVE per block for the 6- / 8-wave tiles, running 5
+// K-tiles ahead of the direct-to-LDS requests - +-0..4 % (profiles/r03_prefetch_wave_ab.txt): neither the memory latency
+// under the ring depth nor the per-barrier episode is what bounds these loops.
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
-    if (stages >= 16 && (tile == 2 || tile == 3) && !(p.flags & LB_GEMM_ROW_STATS) && !((p.flags & LB_GEMM_LN_A) && p.row_stats != nullptr))
-        return lb_gemm_launch_glds_double(p, tile, stages - 16, grid, stream);
-    if (stages >= 16) stages = 0;
-    if (tile == 7) return launch_glds_variant<192, 128, 3, 3, true>(p, grid, stream);            // 3 x 42 KiB
-    if (tile == 5) return launch_glds_variant<256, 256, 2, 4, true>(p, grid, stream);     // 128 KiB: two stages only
+    if (tile == 7) return launch_glds_variant<192, 128, 3, 3>(p, grid, stream);            // 3 x 42 KiB
+    if (tile == 5) return launch_glds_variant<256, 256, 2, 4>(p, grid, stream);     // 128 KiB: two stages only
     if (tile == 4) {
-        if (stages == 3) return launch_glds_variant<256, 128, 3, 4, true>(p, grid, stream);
+        if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);
         return launch_glds_variant<256, 128, 2, 4>(p, grid, stream);
     }
     if (tile == 1) {
-        if (stages == 2) return launch_glds_variant<128, 128, 2, 2, true>(p, grid, stream);
+        if (stages == 2) return launch_glds_variant<128, 128, 2, 2>(p, grid, stream);
         if (stages == 4) return launch_glds_variant<128, 128, 4>(p, grid, stream);
         return launch_glds_variant<128, 128, 3>(p, grid, stream);
     }
     if (tile == 2) {
-        if (stages == 2) return launch_glds_variant<128, 64, 2, 2, true>(p, grid, stream);
+        if (stages == 2) return launch_glds_variant<128, 64, 2, 2>(p, grid, stream);
         if (stages == 4) return launch_glds_variant<128, 64, 4>(p, grid, stream);
         return launch_glds_variant<128, 64, 3>(p, grid, stream);
     }
     if (stages == 2) return launch_glds_variant<64, 64, 2>(p, grid, stream);
-    if (stages == 3) return launch_glds_variant<64, 64, 3, 2, true>(p, grid, stream);
+    if (stages == 3) return launch_glds_variant<64, 64, 3, 2>(p, grid, stream);
     return launch_glds_variant<64, 64, 4>(p, grid, stream);
 }

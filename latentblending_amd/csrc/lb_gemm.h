@@ -88,10 +88,7 @@ template <int TM> struct LbLnRows { float mean[TM], rstd[TM]; };
 
 // RowFn: i -> global output row of the lane's i-th 16-row group (row0 + 16 i for the GEMM kernels; the pixel
 // index of a 2-D spatial tile for the halo conv kernel).
-// STATS (LB_GEMM_ROW_STATS): per row and 32-column slot, (sum, sum of squares) of the fp16 values this epilogue stores go
-// to p.row_stats[slot][M]: the four lanes that share a row (g = 0..3) fold their column quads of a slot, lane g = 0 writes.
-// A slot is 2 column groups of a wave (TN is even, wave column ranges start at multiples of 32).
-template <int TM, int TN, bool GEGLU, bool LNA, bool STATS = false, typename RowFn>
+template <int TM, int TN, bool GEGLU, bool LNA, typename RowFn>
 __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
                                                            RowFn row_of, int col0, int gcol0, const LbLnRows<TM>* ln) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -176,12 +173,6 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
                 }
             }
         }
-        constexpr int NSL = TN / 2 > 0 ? TN / 2 : 1;
-        float st_s[NSL], st_q[NSL];
-        if (STATS) {
-#pragma unroll
-            for (int sl = 0; sl < NSL; ++sl) st_s[sl] = st_q[sl] = 0.f;
-        }
         long crow = m;                  // output row; sub-pixel convs scatter to the 2x-upsampled grid
         if (p.scatter) {
             const int hw = p.Hout * p.Wout;
@@ -218,27 +209,7 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (p.flags & LB_GEMM_GELU) ? lb_gelu_erf(o[r]) : lb_quick_gelu(o[r]);
             }
-            if (STATS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float h = (float)(f16)o[r];           // the value a LayerNorm pass would read back
-                    st_s[j / 2] += h;
-                    st_q[j / 2] += h * h;
-                }
-            }
             lb_gemm_write4(p, crow, m, n, o);
-        }
-        if (STATS) {
-            const int lane = threadIdx.x & 63;
-#pragma unroll
-            for (int sl = 0; sl < NSL; ++sl) {
-                float s = st_s[sl], q = st_q[sl];
-                s += __shfl_xor(s, 16, LB_WAVE); q += __shfl_xor(q, 16, LB_WAVE);
-                s += __shfl_xor(s, 32, LB_WAVE); q += __shfl_xor(q, 32, LB_WAVE);
-                const int ncol = col0 - 4 * (lane >> 4) + sl * 32;          // first column of the slot
-                if ((lane >> 4) == 0 && m_ok && ncol < p.N)
-                    reinterpret_cast<float2*>(p.row_stats)[(long)(ncol >> 5) * p.M + m] = make_float2(s, q);
-            }
         }
     }
 }
@@ -247,13 +218,6 @@ template <int TM, int TN, bool GEGLU, typename RowFn>
 __device__ __forceinline__ void lb_gemm_tile_epilogue_rows(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
                                                            RowFn row_of, int col0, int gcol0) {
     lb_gemm_tile_epilogue_rows_ln<TM, TN, GEGLU, false>(p, acc, row_of, col0, gcol0, (const LbLnRows<TM>*)nullptr);
-}
-
-template <int TM, int TN>
-__device__ __forceinline__ void lb_gemm_tile_epilogue_stats(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
-                                                            int row0, int col0, int gcol0) {
-    lb_gemm_tile_epilogue_rows_ln<TM, TN, false, false, true>(p, acc, [row0](int i) { return row0 + i * 16; }, col0, gcol0,
-                                                              (const LbLnRows<TM>*)nullptr);
 }
 
 template <int TM, int TN, bool GEGLU>

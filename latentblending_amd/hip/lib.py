@@ -32,7 +32,7 @@ class LbGemmParams(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
         ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
-        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_nslots", C.c_int), ("row_stats", C.c_void_p),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int), ("reserved3_", C.c_void_p),
     ]
 
 
@@ -46,7 +46,7 @@ class LbAttnParams(C.Structure):
 
 
 GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU, GEMM_LN_A = 1, 2, 4, 8, 16, 32, 64
-GEMM_QUICK_GELU, GEMM_GELU, GEMM_ROW_STATS = 128, 256, 512
+GEMM_QUICK_GELU, GEMM_GELU = 128, 256
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -69,8 +69,6 @@ SIGNATURES = {
     "lb_gemm_set_tuning": (None, [_i, _i]),
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
-    "lb_gemm_set_prefetch": (None, [_i]),
-    "lb_gemm_set_double_step": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_conv3x3_narrow_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
@@ -121,7 +119,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_prefetch", "lb_gemm_set_double_step", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 
@@ -164,8 +162,3 @@ for _name, (_res, _args) in STUDY_SIGNATURES.items():
         _fn.restype = _res
         _fn.argtypes = _args
         setattr(api, _name, _fn)
-
-if os.environ.get("LB_GEMM_DOUBLE"):            # tuning experiments: double-step small-tile GEMMs
-    api.lb_gemm_set_double_step(int(os.environ["LB_GEMM_DOUBLE"]))
-if os.environ.get("LB_GEMM_PREFETCH"):          # tuning experiments (tools/): L2-prefetch wave of the big GEMM tiles
-    api.lb_gemm_set_prefetch(int(os.environ["LB_GEMM_PREFETCH"]))

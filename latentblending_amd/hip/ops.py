@@ -154,13 +154,10 @@ def subpixel_upsample_weights(w: torch.Tensor, cin_pad: Optional[int] = None):
 
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          flags: int = 0, alpha: float = 1.0, out: Optional[torch.Tensor] = None, splitk_ws: bool = True,
-         conv: Optional[dict] = None, M: Optional[int] = None, ln=None, ln_stats: Optional[torch.Tensor] = None,
-         row_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+         conv: Optional[dict] = None, M: Optional[int] = None, ln=None) -> torch.Tensor:
     """C = epilogue(A . W^T).  A: [M, K] fp16 (or NHWC [B,H,W,C] with ``conv``), W: [N, K] fp16.
     ``conv``: dict(KH, KW, stride, pad, ups) for an implicit-GEMM convolution.
-    ``ln`` = (colsum [N] fp32, eps): LayerNorm over A's columns folded into the GEMM (see ``fold_layernorm``);
-    ``ln_stats``: fp32 [K/32, M, 2] row statistics of A written by its producer (``row_stats`` of that call: fp32
-    [N/32, M, 2] (sum, sum of squares) per 32-column slot of the stored fp16 output) instead of in-loop statistics."""
+    ``ln`` = (colsum [N] fp32, eps): LayerNorm over A's columns folded into the GEMM (see ``fold_layernorm``)."""
     p = LbGemmParams()
     N, K = W.shape
     dev = A.device
@@ -207,13 +204,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     if ln is not None:
         p.flags |= lib.GEMM_LN_A
         p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
-        if ln_stats is not None:
-            p.row_stats, p.ln_nslots = ln_stats.data_ptr(), K // 32
-    if row_stats is not None:
-        p.flags |= lib.GEMM_ROW_STATS
-        p.row_stats = row_stats.data_ptr()
     ws = None
-    if splitk_ws and not (flags & lib.GEMM_GEGLU) and ln is None and row_stats is None:
+    if splitk_ws and not (flags & lib.GEMM_GEGLU) and ln is None:
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)
         p.partial = ws.data_ptr()
     if conv is not None and conv.get("halo"):         # experimental halo-tile 3x3 kernel (csrc/conv3_halo.hip)

@@ -166,12 +166,9 @@ class Emitter:
              residual=None, rowvec=None, rows_per_batch: int = 0, flags: int = 0, alpha: float = 1.0,
              lda: Optional[int] = None, ldc: Optional[int] = None, ldr: Optional[int] = None,
              ld_rowvec: Optional[int] = None, conv: Optional[dict] = None, splitk: bool = True,
-             ln: Optional[Tuple[torch.Tensor, float]] = None, ln_stats: Optional[torch.Tensor] = None,
-             row_stats: Optional[torch.Tensor] = None):
+             ln: Optional[Tuple[torch.Tensor, float]] = None):
         """``ln`` = (colsum [N] fp32, eps): A is consumed through a LayerNorm folded into this GEMM (LB_GEMM_LN_A; W and
-        bias must already carry gamma / beta, see ``NativeUNet._ln_linear``).  With ``ln_stats`` (fp32 [K/32, M, 2]) the row
-        statistics of A are READ from that buffer - the GEMM that produced A wrote them (its ``row_stats``,
-        LB_GEMM_ROW_STATS: fp32 [N/32, M, 2], never split-K) - instead of being accumulated inside the K loop."""
+        bias must already carry gamma / beta, see ``NativeUNet._ln_linear``); row statistics from the A fragments in the K loop."""
         p = LbGemmParams()
         N, K = W.shape
         p.A, p.W, p.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
@@ -197,14 +194,7 @@ class Emitter:
         if ln is not None:
             p.flags |= lib.GEMM_LN_A
             p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
-            if ln_stats is not None:
-                assert K % 32 == 0 and ln_stats.numel() >= (K // 32) * M * 2 and ln_stats.dtype == F32
-                p.row_stats, p.ln_nslots = ln_stats.data_ptr(), K // 32
-        if row_stats is not None:
-            assert ln is None and conv is None and N % 32 == 0 and row_stats.numel() >= (N // 32) * M * 2 and row_stats.dtype == F32
-            p.flags |= lib.GEMM_ROW_STATS
-            p.row_stats = row_stats.data_ptr()
-        if splitk and not (flags & lib.GEMM_GEGLU) and ln is None and row_stats is None:
+        if splitk and not (flags & lib.GEMM_GEGLU) and ln is None:
             p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())
         mult = 4.0 if p.scatter == 2 else 1.0          # (four parities: four times the rows, weights and outputs)

@@ -71,15 +71,10 @@ class NativeUNet:
         ``True``: row statistics accumulated inside the consumer's K loop.  Not for MFMA-bound programs: on MI355X the 64 v_dot2 per
         K-tile and wave cost the MFMA loop more than the 6 us LayerNorm launch they replace
         (profiles/r02_ln_gemm_bench.txt: QKV 57.1 + 6.4 us separate vs 70.0 us fused at B=17; GEGLU 132 + 6 vs 166).
-        ``"stats"``: the GEMM that PRODUCES the hidden state (proj_in, the attention output projections, the
-        feed-forward output) writes per-row (sum, sum of squares) of what it stores from its epilogue
-        (LB_GEMM_ROW_STATS) and the consumer only applies the algebraic fold; producers that the planner runs split-K
-        (B=2 feed-forward outputs) keep a stand-alone LayerNorm behind them.  Also measured SLOWER
-        (profiles/r02_ln_stats_ab.txt: forward at B=17 38.6 -> 42.3 ms with 703 instead of 913 launches, B=2 12.4 -> 12.9):
-        the cost is not the in-loop statistics but the consumer's epilogue, which fetches the statistics and the column
-        sums row by row behind the K loop (an exposed L2 round trip per row group and block).  Both stay tested options."""
+        (A third form - row statistics written by the PRODUCING GEMM's epilogue - was measured slower than the stand-alone
+        LayerNorm at B = 2 and B = 17 alike and removed in round 3: profiles/r02_ln_stats_ab.txt.)"""
         assert cfg.head_dim == 64, "attention kernel is specialised for head_dim 64"
-        assert fuse_layernorm in (False, True, "stats", "auto")
+        assert fuse_layernorm in (False, True, "auto")
         self.cfg, self.device = cfg, torch.device(device)
         self.fuse_layernorm = fuse_layernorm
         self.keep_ln_weights = fuse_layernorm is not True
@@ -351,22 +346,16 @@ class UNetProgram:
                      groups=self.net.cfg.norm_groups)
         h = ar.alloc((M, c))
         mode = self.ln_mode
-        # "stats" mode: the producers of h leave its row statistics in `st`; a producer the planner would run split-K
-        # (its final values are formed by the reduce kernel) cannot, and the LayerNorm behind it stays a launch
-        st = ar.alloc((c // 32, M, 2), F32) if mode == "stats" and c % 32 == 0 else None
-        can_short = st is not None and em.plan(M, c, c)[1] == 1            # proj_in / attention output projections (K = c)
-        can_long = st is not None and em.plan(M, c, 4 * c)[1] == 1         # feed-forward output (K = 4c)
-        em.gemm(n, w[p + ".proj_in.weight"], h, M=M, bias=w[p + ".proj_in.bias"], row_stats=st if can_short else None)
-        have_stats = can_short
+        em.gemm(n, w[p + ".proj_in.weight"], h, M=M, bias=w[p + ".proj_in.bias"])
         ar.release(n)
         for d in range(depth):
             b = f"{p}.transformer_blocks.{d}"
             # --- self attention ---
-            fuse = mode is True or have_stats
+            fuse = mode is True
             qkv = ar.alloc((M, 3 * c))
             if fuse:        # LayerNorm folded into the projection: affine in the epilogue, statistics from the A fragments or from `st`
                 em.gemm(h, w[b + ".attn1.qkv_ln.weight"], qkv, M=M, bias=w[b + ".attn1.qkv_ln.bias"],
-                        ln=(w[b + ".attn1.qkv_ln.colsum"], 1e-5), ln_stats=st if have_stats else None)
+                        ln=(w[b + ".attn1.qkv_ln.colsum"], 1e-5))
             else:
                 ln = ar.alloc((M, c))
                 em.layernorm(h, ln, w[b + ".norm1.weight"], w[b + ".norm1.bias"], M=M, C_=c)
@@ -376,16 +365,13 @@ class UNetProgram:
             em.attention(qkv.data_ptr(), qkv.data_ptr() + c * 2, qkv.data_ptr() + 2 * c * 2, a, B=B, H=heads, Sq=S,
                          Skv=S, valid=S, ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c)
             ar.release(qkv)
-            em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h,
-                    row_stats=st if can_short else None)
-            have_stats = can_short
+            em.gemm(a, w[b + ".attn1.to_out.0.weight"], h, M=M, bias=w[b + ".attn1.to_out.0.bias"], residual=h)
             ar.release(a)
             # --- cross attention (K / V^T of the text context come from the conditioning program) ---
-            fuse = mode is True or have_stats
             q = ar.alloc((M, c))
             if fuse:
                 em.gemm(h, w[b + ".attn2.to_q_ln.weight"], q, M=M, bias=w[b + ".attn2.to_q_ln.bias"],
-                        ln=(w[b + ".attn2.to_q_ln.colsum"], 1e-5), ln_stats=st if have_stats else None)
+                        ln=(w[b + ".attn2.to_q_ln.colsum"], 1e-5))
             else:
                 ln = ar.alloc((M, c))
                 em.layernorm(h, ln, w[b + ".norm2.weight"], w[b + ".norm2.bias"], M=M, C_=c)
@@ -397,30 +383,21 @@ class UNetProgram:
                          self.ctx_kv.data_ptr() + (self.net.n_ctx + off) * 2, a, B=B, H=heads, Sq=S, Skv=CTX_PAD,
                          valid=CTX_TOKENS, ldq=c, ldk=2 * self.net.n_ctx, ldv=2 * self.net.n_ctx, ldo=c)
             ar.release(q)
-            em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h,
-                    row_stats=st if can_short else None)
-            have_stats = can_short
+            em.gemm(a, w[b + ".attn2.to_out.0.weight"], h, M=M, bias=w[b + ".attn2.to_out.0.bias"], residual=h)
             ar.release(a)
             # --- GEGLU feed-forward ---
-            fuse = mode is True or have_stats
             ff = ar.alloc((M, 4 * c))
             if fuse:
                 em.gemm(h, w[b + ".ff.net.0.proj_ln.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj_ln.bias"],
-                        flags=lib.GEMM_GEGLU, ln=(w[b + ".ff.net.0.proj_ln.colsum"], 1e-5),
-                        ln_stats=st if have_stats else None)
+                        flags=lib.GEMM_GEGLU, ln=(w[b + ".ff.net.0.proj_ln.colsum"], 1e-5))
             else:
                 ln = ar.alloc((M, c))
                 em.layernorm(h, ln, w[b + ".norm3.weight"], w[b + ".norm3.bias"], M=M, C_=c)
                 em.gemm(ln, w[b + ".ff.net.0.proj.weight"], ff, M=M, bias=w[b + ".ff.net.0.proj.bias"],
                         flags=lib.GEMM_GEGLU)
                 ar.release(ln)
-            last = d == depth - 1                       # (proj_out follows: nobody reads the statistics)
-            em.gemm(ff, w[b + ".ff.net.2.weight"], h, M=M, bias=w[b + ".ff.net.2.bias"], residual=h,
-                    row_stats=st if can_long and not last else None)
-            have_stats = can_long and not last
+            em.gemm(ff, w[b + ".ff.net.2.weight"], h, M=M, bias=w[b + ".ff.net.2.bias"], residual=h)
             ar.release(ff)
-        if st is not None:
-            ar.release(st)
         out = ar.alloc((B, H, W, c))
         em.gemm(h, w[p + ".proj_out.weight"], out, M=M, bias=w[p + ".proj_out.bias"], residual=x)
         ar.release(h)

@@ -431,52 +431,6 @@ def test_gemm_layernorm_fused(case, tile, results_log):
     check_close(results_log, f"gemm_ln_fused_{'_'.join(map(str, case))}_tile{tile}", got, ref, rel=3e-3, frac=2 ** -7)
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7])
-@pytest.mark.parametrize("case", [(4352, 1280, 1280), (1000, 640, 320), (512, 1280, 5120)])
-def test_gemm_row_stats_and_fold(case, tile, results_log):
-    """LB_GEMM_ROW_STATS + LB_GEMM_LN_A(row_stats): the producer GEMM (bias + residual, written in place like the UNet's
-    output projections) leaves per-row (sum, sum of squares) of the fp16 values it stores, per 32-column slot; the
-    consumer folds the LayerNorm of those rows algebraically from them.  Checked: the statistics themselves against
-    torch on the stored tensor, and producer -> consumer against torch Linear -> LayerNorm -> Linear (-> GEGLU)."""
-    o, l = ops(), lib()
-    M, N, K = case
-    a = rnd(M, K, seed=181)
-    w1 = rnd(N, K, seed=182, scale=K ** -0.5)
-    b1 = rnd(N, seed=183, dtype=torch.float32)
-    res = rnd(M, N, seed=184) * 1.5 + rnd(M, 1, seed=185) * 3.0        # rows with a common offset (mean >> 0)
-    h = res.to(DEV).clone()
-    st = torch.full((N // 32, M, 2), float("nan"), dtype=torch.float32, device=DEV)
-    l.api.lb_gemm_set_tuning(tile, 0)
-    try:
-        o.gemm(a.to(DEV), w1.to(DEV), bias=b1.to(DEV), residual=h, out=h, row_stats=st)
-    finally:
-        l.api.lb_gemm_set_tuning(0, 0)
-    ref_h = a.float() @ w1.float().t() + b1 + res.float()
-    check_close(results_log, f"gemm_rowstats_out_{M}_{N}_{K}_tile{tile}", h, ref_h, rel=3e-3)
-    hs = h.float().cpu().reshape(M, N // 32, 32)
-    s_ref, q_ref = hs.sum(-1).t(), (hs * hs).sum(-1).t()                # [slots, M] of the STORED values
-    assert torch.isfinite(st).all(), "a statistics slot was not written"
-    assert torch.allclose(st[..., 0].cpu(), s_ref, rtol=1e-4, atol=1e-2) and torch.allclose(st[..., 1].cpu(), q_ref, rtol=1e-4, atol=1e-2)
-    # consumer: LayerNorm(h) -> Linear (and GEGLU) with the statistics from the buffer
-    for geglu in (False, True):
-        N2 = 640 if geglu else 384
-        w2 = rnd(N2, N, seed=186, scale=N ** -0.5)
-        b2 = rnd(N2, seed=187, dtype=torch.float32)
-        gamma = 1.0 + 0.2 * rnd(N, seed=188, dtype=torch.float32)
-        beta = 0.1 * rnd(N, seed=189, dtype=torch.float32)
-        ref = F.layer_norm(h.float().cpu(), (N,), gamma, beta, 1e-5) @ w2.float().t() + b2
-        if geglu:
-            hh, gt = ref.chunk(2, dim=-1)
-            ref = hh * F.gelu(gt)
-        wf, colsum, bf = o.fold_layernorm(w2, b2, gamma, beta)
-        l.api.lb_gemm_set_tuning(tile, 0)
-        try:
-            got = o.gemm(h, wf.to(DEV), bias=bf.to(DEV), flags=l.GEMM_GEGLU if geglu else 0, ln=(colsum.to(DEV), 1e-5), ln_stats=st)
-        finally:
-            l.api.lb_gemm_set_tuning(0, 0)
-        check_close(results_log, f"gemm_ln_from_stats_{M}_{N}_{K}_{int(geglu)}_tile{tile}", got, ref, rel=3e-3, frac=2 ** -7)
-
-
 # ------------------------------------------------------------------ attention ----------------
 @pytest.mark.parametrize("case", [(1, 10, 1024, 1024, 1024), (2, 20, 256, 256, 256), (2, 5, 100, 80, 77),
                                   (1, 2, 64, 64, 64), (1, 10, 4096, 80, 77), (3, 4, 200, 200, 200)])
@@ -607,11 +561,10 @@ def test_small_kernels(results_log):
 
 
 # ------------------------------------------------------------------ direct-to-LDS GEMM variant
-@pytest.mark.parametrize("tile,stages", [(t, s) for t in (1, 2, 3, 4, 5, 7) for s in (2, 3, 4)] +
-                         [(3, 20), (3, 22), (3, 24), (2, 20), (2, 22)])
+@pytest.mark.parametrize("stages", [2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7])
 def test_gemm_glds_variant(tile, stages, results_log):
-    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references.  stages = 16 + S: the
-    double-step form of the 4-wave tiles (two K-tiles per barrier, S-stage ring; odd K-tile counts end in a zero tile)."""
+    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references."""
     o, l = ops(), lib()
     l.api.lb_gemm_set_variant(1, stages)
     l.api.lb_gemm_set_tuning(tile, 0)
@@ -723,58 +676,6 @@ def test_conv3x3_halo_against_conv2d(case, results_log):
     finally:
         l.api.lb_gemm_set_halo(1)
     check_close(results_log, f"halo_conv_routed_{'_'.join(map(str, case))}", got2, ref)
-
-
-@pytest.mark.parametrize("tile", [4, 5, 7])
-def test_gemm_prefetch_wave_is_bit_identical(tile, results_log):
-    """lb_gemm_set_prefetch: the extra L2-prefetch wave of the 6- / 8-wave tiles only touches cache lines - results must be
-    bit-identical to the plain kernel (plain and GEGLU, ragged M / N / K tails)."""
-    o, l = ops(), lib()
-    l.api.lb_gemm_set_tuning(tile, 0)
-    try:
-        for (M, N, K) in [(4352, 1280, 1280), (333, 132, 200), (1000, 640, 2560)]:
-            A, W = rnd(M, K, seed=171).to(DEV), rnd(N, K, seed=172, scale=K ** -0.5).to(DEV)
-            bias, res = rnd(N, seed=173, dtype=torch.float32).to(DEV), rnd(M, N, seed=174).to(DEV)
-            l.api.lb_gemm_set_prefetch(0)
-            ref = o.gemm(A, W, bias=bias, residual=res)
-            l.api.lb_gemm_set_prefetch(1)
-            got = o.gemm(A, W, bias=bias, residual=res)
-            assert torch.equal(ref, got), (tile, M, N, K)
-        if tile != 7:
-            A, W = rnd(300, 640, seed=175).to(DEV), rnd(5120, 640, seed=176, scale=640 ** -0.5).to(DEV)
-            l.api.lb_gemm_set_prefetch(0)
-            ref = o.gemm(A, W, flags=l.GEMM_GEGLU)
-            l.api.lb_gemm_set_prefetch(1)
-            assert torch.equal(ref, o.gemm(A, W, flags=l.GEMM_GEGLU))
-    finally:
-        l.api.lb_gemm_set_prefetch(0)
-        l.api.lb_gemm_set_tuning(0, 0)
-
-
-@pytest.mark.parametrize("tile,stages", [(3, 24), (3, 20), (2, 22)])
-def test_gemm_double_step_layernorm_fold(tile, stages, results_log):
-    """The double-step kernels with the LayerNorm folded into the A operand (LB_GEMM_LN_A, in-loop statistics): the B = 2
-    anchor programs run their QKV / to_q / GEGLU projections this way."""
-    o, l = ops(), lib()
-    M, C = 512, 1280
-    x = rnd(M, C, seed=181)
-    gamma, beta = 1 + 0.1 * rnd(C, seed=182, dtype=torch.float32), 0.1 * rnd(C, seed=183, dtype=torch.float32)
-    for geglu in (False, True):
-        N = 2560 if geglu else 1280
-        w, b = rnd(N, C, seed=184, scale=C ** -0.5), rnd(N, seed=185, dtype=torch.float32, scale=0.1)
-        y = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) @ w.float().t() + b
-        if geglu:
-            h, gate = y.chunk(2, dim=-1)
-            y = h * F.gelu(gate)
-        wf, colsum, b2 = o.fold_layernorm(w, b, gamma, beta)
-        l.api.lb_gemm_set_variant(1, stages)
-        l.api.lb_gemm_set_tuning(tile, 0)
-        try:
-            got = o.gemm(x.to(DEV), wf.to(DEV), bias=b2.to(DEV), flags=l.GEMM_GEGLU if geglu else 0, ln=(colsum.to(DEV), 1e-5))
-        finally:
-            l.api.lb_gemm_set_variant(-1, 0)
-            l.api.lb_gemm_set_tuning(0, 0)
-        check_close(results_log, f"double_step_ln_fold_t{tile}s{stages}_{'geglu' if geglu else 'plain'}", got, y, rel=3e-3, frac=2 ** -7)
 
 
 @pytest.mark.parametrize("case", [(2, 32, 128, 3, True), (1, 64, 320, 4, False), (3, 16, 64, 7, True)])

@@ -45,10 +45,10 @@ def make_pair(turbo=True, ucfg=None, vcfg=None, seed=0):
 
 
 @pytest.mark.parametrize("B,L,fused_ln", [(1, 16, False), (2, 16, False), (3, 32, False), (2, 16, True), (3, 32, True),
-                                          (2, 16, "stats"), (3, 32, "stats"), (17, 32, "stats")])
+                                          (2, 16, "auto"), (17, 32, "auto")])
 def test_unet_tiny_matches_oracle(B, L, fused_ln, results_log):
-    """fused_ln: the LayerNorms folded into their consumer GEMMs (LB_GEMM_LN_A; an option, off by default) - True: row
-    statistics inside the consumer's K loop; "stats": written by the producing GEMM's epilogue (LB_GEMM_ROW_STATS)."""
+    """fused_ln: the LayerNorms folded into their consumer GEMMs (LB_GEMM_LN_A, row statistics inside the consumer's K
+    loop) - True: always; "auto" (the default): only in launch-bound programs (<= 1024 tokens at the deepest level)."""
     n = native()
     cfg = R.tiny_unet_cfg()
     w = R.make_weights(R.unet_spec(cfg), 0)
@@ -60,10 +60,13 @@ def test_unet_tiny_matches_oracle(B, L, fused_ln, results_log):
     ids = torch.tensor([[128.0, 128.0, 0.0, 0.0, 128.0, 128.0]] * B)
     ref = R.unet_forward(cfg, w, x, torch.tensor(499.0), ctx, te, ids)
     prog = net.build(B, L)
+    if fused_ln == "auto":
+        assert prog.ln_mode == (B * (L // 4) ** 2 <= 1024)
+        assert ("lb_layernorm_f16" in prog.prog_step.op_names()) == (not prog.ln_mode)
     prog.set_conditioning(ctx.to(DEV), te.to(DEV), ids.to(DEV))
     got = prog.forward(x.to(DEV), torch.full((B,), 499.0)).clone()
     r = rel_l2(got, ref)
-    results_log[f"unet_tiny_B{B}_L{L}{'_fusedln' + ('' if fused_ln is True else '_stats') if fused_ln else ''}_rel_l2"] = r
+    results_log[f"unet_tiny_B{B}_L{L}{'_fusedln' + ('' if fused_ln is True else '_auto') if fused_ln else ''}_rel_l2"] = r
     print(f"[parity] unet tiny B={B} L={L}: rel_l2={r:.3e} ops={prog.prog_step.num_ops}+{prog.prog_cond.num_ops}")
     assert torch.isfinite(got).all() and r <= 1e-2
     # graph replay == eager replay, bit for bit; a second timestep reuses the conditioning program

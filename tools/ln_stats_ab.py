@@ -1,5 +1,5 @@
-"""A/B of the LayerNorm handling inside the full SDXL UNet programs: stand-alone LayerNorm launches (default) vs the
-statistics written by the producing GEMM's epilogue and folded algebraically into the consumer (fuse_layernorm="stats").
+"""A/B of the LayerNorm handling inside the full SDXL UNet programs: stand-alone LayerNorm launches vs the LayerNorm folded
+into the consuming GEMMs (fuse_layernorm=True: row statistics inside the K loop; "auto" picks per program from this A/B).
 hipGraph replay of the B=2 and B=17 step programs at 512^2, same synthetic weights.
 Usage: LB_SYNTH_CACHE=/tmp python tools/ln_stats_ab.py > profiles/r02_ln_stats_ab.txt"""
 import os
@@ -34,7 +34,7 @@ def main():
     cdir = os.environ.get("LB_SYNTH_CACHE")
     cfile = os.path.join(cdir, "lb_synth_seed0.pt") if cdir else None
     outs = {}
-    modes = [False] + [{"true": True, "stats": "stats"}[a] for a in sys.argv[1:] if a in ("true", "stats")] if len(sys.argv) > 1 else [False, "stats"]
+    modes = [False, True]         # stand-alone LayerNorms vs folded into the consumers (in-loop statistics)
     for mode in modes:
         t0 = time.time()
         prov = N.SyntheticProvider(0, cache_file=cfile)

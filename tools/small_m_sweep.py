@@ -81,11 +81,7 @@ def main():
         auto, _ = timed_graph(ps, 0, 0, 0)
         row = {}
         for tile in (3, 2, 1):
-            for stages in (2, 3, 4, 20, 22, 24):        # 16 + S = double-step form (two K-tiles per barrier)
-                if tile == 1 and stages > 4:
-                    continue
-                if tile == 2 and stages == 24:
-                    continue
+            for stages in (2, 3, 4):
                 for sk in ((1,) if geglu else (1, 2, 4)):
                     if K // 64 // sk < 2:
                         continue
