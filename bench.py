@@ -133,8 +133,8 @@ def gemm_family_profile(pipe, launches):
                 tot[key + "_ms"] += t * cnt
                 tot[key + "_flops"] += a["flops"] * cnt
                 ai += 1
-            elif n in ("lb_groupnorm_nhwc", "lb_layernorm_f16"):
-                k = "gn" if n == "lb_groupnorm_nhwc" else "ln"
+            elif n in ("lb_groupnorm_nhwc", "lb_groupnorm_from_stats", "lb_layernorm_f16"):
+                k = "ln" if n == "lb_layernorm_f16" else "gn"
                 while ni < len(nlog) and nlog[ni]["op"] != n:      # (the log is in emission order, both kinds mixed)
                     ni += 1
                 tot[k + "_ms"] += t * cnt
@@ -255,7 +255,8 @@ def roofline_blocks(prof, launch_counts, device):
          "per_transition": {"tflop": prof["attn_flops"] / 1e12, "ms": prof["attn_ms"], "launches": prof["attn_launches"],
                             "self_TFLOPs": _tf(prof["attn_self_flops"], prof["attn_self_ms"]), "self_ms": prof["attn_self_ms"],
                             "cross_TFLOPs": _tf(prof["attn_cross_flops"], prof["attn_cross_ms"]), "cross_ms": prof["attn_cross_ms"]}},
-        {"kernel": "gn_partial_kernel + gn_apply_kernel (GroupNorm + SiLU, 3 passes)", "bound": "hbm",
+        {"kernel": "gn_partial_kernel + gn_apply_kernel / gn_fold_stats_kernel + gn_apply_kernel (GroupNorm + SiLU: 6 B per element, "
+                   "4 B where the producing conv's epilogue left the statistics)", "bound": "hbm",
          "achieved": gn, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gn / HBM_PEAK_GBS,
          "per_transition": {"ms": prof["gn_ms"], "launches": prof["gn_launches"], "GB": prof["gn_bytes"] / 1e9}},
     ]
@@ -419,6 +420,19 @@ def secondary_lines(pipe, args, branches):
                     "frontier_rounds": be.stats.get("frontier_rounds", 0) / 3, "speculation_hit_rate": (ev - dr) / ev if ev else None})
     except Exception as exc:
         out.append({"name": "cfg2 under a skewed metric", "error": repr(exc)})
+    try:    # opt-in engine feature, NOT the metric: the reference performs these forwards, so the headline does too
+        be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+        be.elide_dead_steps = True
+        be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+        be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+        be.set_branching(nmb_max_branches=branches)
+        before = pipe.stats["unet_samples"]
+        n, dt = timed(be, 3, 1)
+        out.append({"name": "cfg2 with elide_dead_steps=True (SURVEY C15: the mid branches' step at idx_injection is overwritten by the next "
+                            "step's crossfeed, coefficient 1.0; bit-identical frames, tests/test_native_gpu.py)", "value": n / dt, "unit": "frames/s",
+                    "ms_per_step": dt * 1e3, "unet_samples_per_transition": (pipe.stats["unet_samples"] - before) / 4})
+    except Exception as exc:
+        out.append({"name": "cfg2 with elide_dead_steps", "error": repr(exc)})
     try:
         base_pipe = N.NativeSDXLPipe(turbo=False, unet_native=pipe.unet_native, vae_native=pipe.vae_native, device=str(pipe.device),
                                      allow_synthetic=True)

@@ -77,6 +77,10 @@ class BlendingEngine:
         #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
+        self.elide_dead_steps = False       # opt-in (native fused wavefront): skip mid steps the next step's crossfeed (coefficient
+        #                                     exactly 1.0, the Turbo defaults) overwrites completely - bit-identical frames, fewer
+        #                                     UNet forwards than the reference performs; tree_latents entries of the
+        #                                     skipped steps are None
         self.seed1 = 0
         self.seed2 = 0
         self.prompt1 = ""
@@ -479,8 +483,13 @@ class BlendingEngine:
             [self.get_noise(self.seed1), self.get_noise(self.seed2)],
             [self.get_mixed_conditioning(gaps[k][2])[0] for k in mine], [gaps[k][2] for k in mine],
             [coeffs] * len(mine), idx_injection, steps, self.guidance_scale, [guid[k] for k in mine],
-            noise_slots=(len(gaps), mine) if farm else None)
-        frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
+            noise_slots=(len(gaps), mine) if farm else None, elide_dead_steps=self.elide_dead_steps and not farm)
+        if farm and farm.rank != 0:
+            # the anchors' FRAMES come from rank 0 in the broadcast below: only their owner decodes them (at 8 ranks the
+            # decode batch of a non-owner halves: 2 mid frames instead of 2 + 2)
+            frames = [None, None] + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])
+        else:
+            frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
         if farm:    # C1: rank 0's anchors (stacks + frames) become everybody's - bit-identical parents / end frames on all ranks
             (first, last), anchor_frames = farm.share_anchor_pair([first, last], frames[:2], 0, steps, self._frame_from_u8,
                                                                   self._latent_chw(), (self.dh.height_img, self.dh.width_img))

@@ -297,7 +297,15 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         // across the MFMA loop - which it then spills around this epilogue)
         int col0 = n0 + wave_n * (BN / 2) + 4 * g;
         asm volatile("" : "+v"(col0));
-        if (!(study & 1)) lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
+        if (!(study & 1)) {
+            if (p.flags & LB_GEMM_CH_STATS) {   // (wave-uniform) GroupNorm statistics of the stored tile: row block (item / n_blocks) * 4 + wave_m
+                float2* chst = reinterpret_cast<float2*>(p.ch_stats) + ((long)(item / n_blocks) * 4 + wave_m) * p.N;
+                lb_gemm_tile_epilogue_rows_ln<TM, TN, false, false, true>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0,
+                                                                          (const LbLnRows<TM>*)nullptr, chst);
+            } else {
+                lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
+            }
+        }
         else if (acc[0][0][0] == 12345.678f) *(float*)p.C = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];   // (keeps the MFMAs alive)
         if (!more) break;
 #pragma unroll
@@ -378,6 +386,7 @@ int lb_upconv_halo_eligible(const LbGemmParams& p) {
 }
 
 int lb_upconv_halo_launch(LbGemmParams p, hipStream_t stream) {
+    LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS) || p.ch_stats != nullptr, "halo upconv: LB_GEMM_CH_STATS needs ch_stats");
     if (p.alpha == 0.f) p.alpha = 1.f;
     p.splitk = 1;
     return lb_upconv_halo_eligible(p) == 32 ? launch_halo<128, 32, 2>(p, stream) : launch_halo<128, 16, 2>(p, stream);
@@ -410,6 +419,8 @@ long lb_conv3x3_halo_blocks(const LbGemmParams& p) {
 }
 
 int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream) {
+    LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS) || (p.ch_stats != nullptr && !(p.flags & LB_GEMM_TRANS_OUT)),
+               "halo conv: LB_GEMM_CH_STATS needs ch_stats and a row-major output");
     if (p.alpha == 0.f) p.alpha = 1.f;
     p.splitk = 1;
     return lb_conv3x3_halo_eligible(p) == 32 ? launch_halo<128, 32>(p, stream) : launch_halo<128, 16>(p, stream);

@@ -528,6 +528,8 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     if (g_halo != 0 && !g_force_tile && lb_conv3x3_narrow_eligible(p))      // N <= 16: conv_out of the VAE / UNet (conv3_narrow.hip)
         LB_DISPATCH("lb_conv3x3_narrow_f16", lb_conv3x3_narrow_launch(p, s));
     if (use_halo(p)) LB_DISPATCH("lb_conv3x3_halo_f16", lb_conv3x3_halo_launch(p, s));
+    LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS), "lb_gemm_f16: LB_GEMM_CH_STATS is implemented by the halo-tile conv kernels only "
+                                              "(check lb_gemm_plan == 6 / lb_conv_halo_plan before asking for it)");
     int tile = 0, splitk = 1;
     long nblk = 0;
     gemm_plan(p, tile, splitk, nblk);

@@ -88,9 +88,13 @@ template <int TM> struct LbLnRows { float mean[TM], rstd[TM]; };
 
 // RowFn: i -> global output row of the lane's i-th 16-row group (row0 + 16 i for the GEMM kernels; the pixel
 // index of a 2-D spatial tile for the halo conv kernel).
-template <int TM, int TN, bool GEGLU, bool LNA, typename RowFn>
+// CHST (LB_GEMM_CH_STATS, halo conv kernels): per output column, (sum, sum of squares) over the wave's 16 TM rows of the
+// values this epilogue STORES (after the fp16 rounding when the output is fp16) go to chst[n] (float2): each lane sums its
+// TM rows, the 16 lanes that share a column quad (l16 = 0..15) fold through wave shuffles in a fixed order, l16 == 0 writes.
+template <int TM, int TN, bool GEGLU, bool LNA, bool CHST = false, typename RowFn>
 __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
-                                                           RowFn row_of, int col0, int gcol0, const LbLnRows<TM>* ln) {
+                                                           RowFn row_of, int col0, int gcol0, const LbLnRows<TM>* ln,
+                                                           float2* chst = nullptr) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (GEGLU) {
         constexpr int TP = TN / 2 > 0 ? TN / 2 : 1;
@@ -132,6 +136,13 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             }
         }
         return;
+    }
+    float cs_s[CHST ? TN : 1][4], cs_q[CHST ? TN : 1][4];
+    if (CHST) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs_s[j][r] = cs_q[j][r] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -209,7 +220,32 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (p.flags & LB_GEMM_GELU) ? lb_gelu_erf(o[r]) : lb_quick_gelu(o[r]);
             }
+            if (CHST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float h = (p.flags & LB_GEMM_OUT_F32) ? o[r] : (float)(f16)o[r];   // the value a GroupNorm pass would read back
+                    cs_s[j][r] += h;
+                    cs_q[j][r] += h * h;
+                }
+            }
             lb_gemm_write4(p, crow, m, n, o);
+        }
+    }
+    if (CHST) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = col0 + j * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = cs_s[j][r], q = cs_q[j][r];
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    s += __shfl_xor(s, d, LB_WAVE);
+                    q += __shfl_xor(q, d, LB_WAVE);
+                }
+                if ((lane & 15) == 0 && n < p.N) chst[n + r] = make_float2(s, q);
+            }
         }
     }
 }

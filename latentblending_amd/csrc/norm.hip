@@ -280,6 +280,76 @@ extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, con
 }
 
 // ------------------------------------------------------------------------------------------
+// GroupNorm from statistics the PRODUCING conv left behind (LB_GEMM_CH_STATS, conv3_halo.hip): ch_stats holds, per
+// (64-pixel row block, channel), (sum, sum of squares) of the stored values.  gn_fold_stats folds them per (sample, group)
+// in float64 - thread t takes rows t, t + 256, ... (all channels of the group), then a fixed-order block reduction - into
+// the SAME partial[b][0][group] slot layout gn_apply_kernel consumes (nchunk = 1): x is read once, by the apply pass.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_fold_stats_kernel(const float2* __restrict__ ch_stats, double* __restrict__ partial,
+                                                            int C, int groups, int rows_per_sample) {
+    __shared__ double red_s[256], red_q[256];
+    const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups;
+    const float2* base = ch_stats + ((long)b * rows_per_sample) * C + grp * cpg;
+    double s = 0, q = 0;
+    for (int r = tid; r < rows_per_sample; r += 256) {
+        const float2* row = base + (long)r * C;
+        for (int c = 0; c < cpg; ++c) {
+            const float2 v = row[c];
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+    }
+    red_s[tid] = s;
+    red_q[tid] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) { red_s[tid] += red_s[tid + w]; red_q[tid] += red_q[tid + w]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double* out = partial + ((long)b * groups + grp) * 2;
+        out[0] = red_s[0];
+        out[1] = red_q[0];
+    }
+}
+
+static int groupnorm_from_stats_impl(const void* x, void* y, const float* gamma, const float* beta, const float* ch_stats,
+                                     void* workspace, int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,
+                                     int x_is_f32, int rows_per_sample, hipStream_t stream) {
+    double* partial = (double*)workspace;
+    hipLaunchKernelGGL(gn_fold_stats_kernel, dim3(groups, B), dim3(256), 0, stream, (const float2*)ch_stats, partial, C, groups,
+                       rows_per_sample);
+    int rc = lb_check_launch("lb_groupnorm_from_stats(fold)");
+    if (rc) return rc;
+    const int vecs = C / 8;
+    const int rows = vecs <= 256 ? 256 / vecs : 1;
+    int want2 = (4096 + B - 1) / B;
+    int apx = (HW + want2 - 1) / want2;
+    const int min_px = 4 * rows;
+    if (apx < min_px) apx = min_px;
+    const int achunks = (HW + apx - 1) / apx;
+    dim3 grid2((unsigned)achunks, B);
+    if (x_is_f32)
+        hipLaunchKernelGGL((gn_apply_kernel<float>), grid2, dim3(256), 0, stream, (const float*)x,
+                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, 1, eps, silu, apx);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<f16>), grid2, dim3(256), 0, stream, (const f16*)x,
+                           partial, gamma, beta, (f16*)y, HW, C, ldx, ldy, groups, 1, eps, silu, apx);
+    return lb_check_launch("lb_groupnorm_from_stats(apply)");
+}
+
+extern "C" int lb_groupnorm_from_stats(const void* x, void* y, const float* gamma, const float* beta, const float* ch_stats,
+                                       void* workspace, int B, int HW, int C, int ldx, int ldy, int groups, float eps,
+                                       int silu, int x_is_f32, int stat_rows_per_sample, void* stream) {
+    LB_REQUIRE(B > 0 && HW > 0 && C > 0 && stat_rows_per_sample > 0 && ch_stats != nullptr, "lb_groupnorm_from_stats: sizes");
+    LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && C <= 4096, "lb_groupnorm_from_stats: C/ld multiple of 8, C <= 4096");
+    LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_from_stats: groups");
+    LB_DISPATCH("lb_groupnorm_from_stats", groupnorm_from_stats_impl(x, y, gamma, beta, ch_stats, workspace, B, HW, C, ldx, ldy,
+                                                                     groups, eps, silu, x_is_f32, stat_rows_per_sample, s));
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension: one wave per row, row kept in registers (C <= 2048).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) layernorm_kernel(const f16* __restrict__ x,

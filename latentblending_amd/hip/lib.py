@@ -32,7 +32,7 @@ class LbGemmParams(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
         ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
-        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int), ("reserved3_", C.c_void_p),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int), ("ch_stats", C.c_void_p),
     ]
 
 
@@ -46,7 +46,7 @@ class LbAttnParams(C.Structure):
 
 
 GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU, GEMM_LN_A = 1, 2, 4, 8, 16, 32, 64
-GEMM_QUICK_GELU, GEMM_GELU = 128, 256
+GEMM_QUICK_GELU, GEMM_GELU, GEMM_CH_STATS = 128, 256, 512
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
     "lb_groupnorm_set_l3_chunk": (None, [_l]),
     "lb_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "lb_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "lb_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lb_attn_fwd_d64": (_i, [C.POINTER(LbAttnParams), _vp]),
     "lb_attn_set_tuning": (None, [_i]),

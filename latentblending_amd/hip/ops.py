@@ -154,7 +154,7 @@ def subpixel_upsample_weights(w: torch.Tensor, cin_pad: Optional[int] = None):
 
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          flags: int = 0, alpha: float = 1.0, out: Optional[torch.Tensor] = None, splitk_ws: bool = True,
-         conv: Optional[dict] = None, M: Optional[int] = None, ln=None) -> torch.Tensor:
+         conv: Optional[dict] = None, M: Optional[int] = None, ln=None, ch_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(A . W^T).  A: [M, K] fp16 (or NHWC [B,H,W,C] with ``conv``), W: [N, K] fp16.
     ``conv``: dict(KH, KW, stride, pad, ups) for an implicit-GEMM convolution.
     ``ln`` = (colsum [N] fp32, eps): LayerNorm over A's columns folded into the GEMM (see ``fold_layernorm``)."""
@@ -204,6 +204,9 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     if ln is not None:
         p.flags |= lib.GEMM_LN_A
         p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
+    if ch_stats is not None:                          # halo-tile convs only: GroupNorm statistics of the stored output
+        p.flags |= lib.GEMM_CH_STATS
+        p.ch_stats = ch_stats.data_ptr()
     ws = None
     if splitk_ws and not (flags & lib.GEMM_GEGLU) and ln is None:
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)
@@ -234,6 +237,31 @@ def groupnorm_nhwc(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, gro
     ws = torch.empty(api.lb_groupnorm_workspace_bytes(B, groups) // 8, dtype=F64, device=x.device)
     api.lb_groupnorm_nhwc(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(),
                           B, HW, C, C, C, groups, eps, int(silu), int(x.dtype == F32), stream_ptr())
+    return y
+
+
+def conv_halo_plan(B: int, H: int, W: int, cin: int, cout: int, ks: int = 3):
+    """(kind, tile width, work items, grid) of the halo-tile kernel for this conv geometry (kind 0: not eligible)."""
+    p = LbGemmParams()
+    p.conv, p.M, p.N, p.K = 1, B * H * W, cout, ks * ks * cin
+    p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.KH, p.KW, p.stride, p.ldx = H, W, H, W, cin, ks, ks, 1, cin
+    p.pad, p.scatter = (1, 0) if ks == 3 else (0, 2)
+    p.zero_page = 64
+    kind, tw, items, grid = C.c_int(), C.c_int(), C.c_long(), C.c_long()
+    api.lb_conv_halo_plan(C.byref(p), C.byref(kind), C.byref(tw), C.byref(items), C.byref(grid))
+    return kind.value, tw.value, items.value, grid.value
+
+
+def groupnorm_from_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+                         ch_stats: torch.Tensor, rows_per_sample: int) -> torch.Tensor:
+    """GroupNorm of x [B, H, W, C] whose (sum, sum of squares) per (64-pixel row block, channel) the producing conv left in
+    ``ch_stats`` ([B * rows_per_sample, C, 2] fp32, LB_GEMM_CH_STATS)."""
+    B, C_ = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C_)
+    y = torch.empty(x.shape, dtype=F16, device=x.device)
+    ws = torch.empty(api.lb_groupnorm_workspace_bytes(B, groups) // 8, dtype=F64, device=x.device)
+    api.lb_groupnorm_from_stats(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ch_stats.data_ptr(), ws.data_ptr(),
+                                B, HW, C_, C_, C_, groups, eps, int(silu), int(x.dtype == F32), rows_per_sample, stream_ptr())
     return y
 
 

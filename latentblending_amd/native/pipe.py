@@ -385,7 +385,7 @@ class StableDiffusionXLPipeline:
                              mid_conds: Sequence[tuple], mid_fracts: Sequence[float],
                              mid_coeffs: Sequence[Sequence[float]], idx_injection: int, num_inference_steps: int,
                              guidance_anchor: float, guidance_mids: Sequence[float],
-                             noise_slots: Optional[Tuple[int, Sequence[int]]] = None):
+                             noise_slots: Optional[Tuple[int, Sequence[int]]] = None, elide_dead_steps: bool = False):
         """Both anchors AND a set of mid branches whose parents are the anchors, in one wavefront.
 
         A mid branch at step i only needs the anchors' latents of step i-1 (its start latent and its
@@ -395,7 +395,12 @@ class StableDiffusionXLPipeline:
         ``steps`` small + (steps-idx) large ones.  Arithmetic per sample is the same as in the
         separate runs.  Returns (trajectory anchor 1, trajectory anchor 2, [mid trajectories]).
         ``noise_slots`` = (n_total, my_indices) as in ``native_run_diffusion_batch`` (farm: every rank runs both
-        anchors plus its own share of the round's mid branches)."""
+        anchors plus its own share of the round's mid branches).
+        ``elide_dead_steps`` (opt-in): a mid step whose result the NEXT step's crossfeed overwrites
+        completely (crossfeed coefficient exactly 1.0 - the SDXL-Turbo defaults, reference blending_engine.py:193-199,
+        452-457 and diffusers_holder.py:322-324: slerp(x, target, 1.0) == target) is not computed: that step runs the
+        anchors only, the mids' trajectory entry is ``None``.  Frames and final latents are bit-identical (noise draws
+        are still consumed in the same order); the reference itself performs the dead forward, so the default is off."""
         A, G = 2, len(mid_conds)
         sched, steps = self.scheduler, num_inference_steps
         if sched.num_inference_steps != steps:
@@ -425,7 +430,9 @@ class StableDiffusionXLPipeline:
             return prog
 
         # G == 0: a farm rank that owns no mid branch of the round (fewer gaps than ranks) still runs both anchors
-        prog_a = prepared(list(anchor_conds)) if (idx_injection > 0 or G == 0) else None
+        dead = [bool(elide_dead_steps) and G > 0 and i >= idx_injection and i + 1 < steps and
+                all(float(mid_coeffs[g][i + 1]) == 1.0 for g in range(G)) for i in range(steps)]
+        prog_a = prepared(list(anchor_conds)) if (idx_injection > 0 or G == 0 or any(dead)) else None
         prog_all = prepared(list(anchor_conds) + list(mid_conds)) if G else prog_a
         stream = torch.cuda.current_stream().cuda_stream
         rows_a = [sched.step_row(i, all_g[0]) for i in range(steps)]
@@ -452,15 +459,19 @@ class StableDiffusionXLPipeline:
         coef_dev = torch.tensor([[float(mid_coeffs[g][i]) for g in range(G)] for i in range(steps)],
                                 dtype=torch.float64, device=self.device) if G else None
         for i in range(steps):
-            if i < idx_injection or G == 0:
+            if i < idx_injection or G == 0 or dead[i]:
                 prog, lat, params, n = prog_a, lat_a, par_a[i], A
                 noise = noise_a[i] if noise_a is not None else None
+                if dead[i] and i == idx_injection:      # (the next step's crossfeed replaces this value bit for bit)
+                    lat_m = torch.zeros((G,) + tuple(lat_a.shape[1:]), dtype=F16, device=self.device)
             else:
                 prev1, prev2 = traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous()
                 mix_prev = ops.slerp_strided(prev1, prev2, fr_dev, n_lat, broadcast0=True, broadcast1=True)   # parental mix of step i-1
                 self.stats["slerps"] += G
                 if i == idx_injection:
                     lat_m = mix_prev.view(G, *lat_a.shape[1:])
+                elif dead[i - 1]:
+                    assert all(float(mid_coeffs[g][i]) == 1.0 for g in range(G))
                 nfeed = sum(1 for g in range(G) if mid_coeffs[g][i] > 0)
                 if nfeed:       # (a coefficient of 0 returns the first operand bit-exactly, like the reference's skipped slerp)
                     lat_m = ops.slerp_strided(lat_m.contiguous().view(G, n_lat), mix_prev, coef_dev[i], n_lat).view(G, *lat_a.shape[1:])
@@ -477,7 +488,10 @@ class StableDiffusionXLPipeline:
             lat_a = out[:A]
             traj_a[0].append(out[0:1])
             traj_a[1].append(out[1:2])
-            if i >= idx_injection and G:
+            if i >= idx_injection and G and dead[i]:
+                for g in range(G):
+                    traj_m[g].append(None)
+            elif i >= idx_injection and G:
                 lat_m = out[A:]
                 for g in range(G):
                     traj_m[g].append(out[A + g:A + g + 1])

@@ -55,6 +55,10 @@ class Arena:
     def release(self, t: Optional[torch.Tensor]) -> None:
         if t is None:
             return
+        st = getattr(t, "_lb_chstats", None)     # statistics buffer of a conv output nobody normalised: goes back with it
+        if st is not None:
+            t._lb_chstats = None
+            self.release(st[0])
         raw = getattr(t, "_lb_raw", None)
         if raw is None:
             return
@@ -166,7 +170,7 @@ class Emitter:
              residual=None, rowvec=None, rows_per_batch: int = 0, flags: int = 0, alpha: float = 1.0,
              lda: Optional[int] = None, ldc: Optional[int] = None, ldr: Optional[int] = None,
              ld_rowvec: Optional[int] = None, conv: Optional[dict] = None, splitk: bool = True,
-             ln: Optional[Tuple[torch.Tensor, float]] = None):
+             ln: Optional[Tuple[torch.Tensor, float]] = None, ch_stats: Optional[torch.Tensor] = None):
         """``ln`` = (colsum [N] fp32, eps): A is consumed through a LayerNorm folded into this GEMM (LB_GEMM_LN_A; W and
         bias must already carry gamma / beta, see ``NativeUNet._ln_linear``); row statistics from the A fragments in the K loop."""
         p = LbGemmParams()
@@ -194,6 +198,10 @@ class Emitter:
         if ln is not None:
             p.flags |= lib.GEMM_LN_A
             p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
+        if ch_stats is not None:       # halo-tile convs only (see halo_stat_rows): GroupNorm statistics of the stored output
+            assert conv is not None and ch_stats.dtype == F32
+            p.flags |= lib.GEMM_CH_STATS
+            p.ch_stats = ch_stats.data_ptr()
         if splitk and not (flags & lib.GEMM_GEGLU) and ln is None:
             p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())
@@ -213,6 +221,29 @@ class Emitter:
         api.lb_gemm_plan(C.byref(p), C.byref(t), C.byref(sk), C.byref(nb))
         return t.value, sk.value
 
+    def halo_stat_rows(self, B: int, H: int, W: int, cin: int, cout: int, ks: int = 3) -> int:
+        """Rows per sample of the LB_GEMM_CH_STATS buffer ([B * rows][cout] float2) if a 3x3 conv (ks = 3) or a one-launch
+        sub-pixel upsampler conv (ks = 2) of this geometry runs on the halo-tile kernel - whose epilogue can leave the
+        GroupNorm statistics of what it stores - else 0 (the consumer then runs the two-pass GroupNorm)."""
+        p = LbGemmParams()
+        p.conv, p.M, p.N, p.K = 1, B * H * W, cout, ks * ks * cin
+        p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.KH, p.KW, p.stride, p.ldx = H, W, H, W, cin, ks, ks, 1, cin
+        p.pad, p.scatter = (1, 0) if ks == 3 else (0, 2)
+        p.zero_page = self.zero_page.data_ptr()
+        if ks == 3:
+            t, sk, nb = C.c_int(), C.c_int(), C.c_long()
+            api.lb_gemm_plan(C.byref(p), C.byref(t), C.byref(sk), C.byref(nb))
+            if t.value != 6:
+                return 0
+        elif not self.upconv_one_launch(B, H, W, cin, cout):
+            return 0
+        kind, tw, items, grid = C.c_int(), C.c_int(), C.c_long(), C.c_long()
+        api.lb_conv_halo_plan(C.byref(p), C.byref(kind), C.byref(tw), C.byref(items), C.byref(grid))
+        if kind.value != ks:
+            return 0
+        n_blocks = (cout + 127) // 128
+        return int(items.value // n_blocks // B * 4)
+
     @staticmethod
     def upconv_one_launch(B: int, H: int, W: int, cin: int, cout: int) -> bool:
         """The halo kernel's sub-pixel form takes this upsampler conv in one launch (else: four implicit-GEMM launches)."""
@@ -221,7 +252,15 @@ class Emitter:
         return shape_ok and blocks >= 96
 
     def groupnorm(self, x: torch.Tensor, out: torch.Tensor, gamma, beta, *, B: int, HW: int, C_: int,
-                  eps: float, silu: bool, groups: int = 32, ldx: Optional[int] = None):
+                  eps: float, silu: bool, groups: int = 32, ldx: Optional[int] = None,
+                  ch_stats: Optional[Tuple[torch.Tensor, int]] = None):
+        """``ch_stats`` = (buffer, rows per sample) left by the conv that produced ``x`` (LB_GEMM_CH_STATS): one pass over x."""
+        if ch_stats is not None:
+            api.lb_groupnorm_from_stats(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ch_stats[0].data_ptr(),
+                                        self._gn_ws(B, groups).data_ptr(), B, HW, C_, ldx or C_, C_, groups, eps, int(silu),
+                                        int(x.dtype == F32), int(ch_stats[1]), _stream())
+            self.norm_log.append({"op": "lb_groupnorm_from_stats", "bytes": float(B * HW * C_) * (x.element_size() + 2)})
+            return out
         api.lb_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                               self._gn_ws(B, groups).data_ptr(), B, HW, C_, ldx or C_, C_, groups, eps,
                               int(silu), int(x.dtype == F32), _stream())

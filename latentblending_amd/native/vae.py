@@ -43,6 +43,7 @@ class VAEConfig:
     scaling_factor: float = 0.13025
     force_upcast: bool = True
     stream_fp16_scaled: bool = True      # residual stream as fp16 * 2^-4 (False: fp32 stream)
+    fuse_gn_stats: bool = True           # GroupNorm statistics from the producing conv's epilogue (LB_GEMM_CH_STATS): one pass over x
 
     @property
     def scale_factor(self) -> int:
@@ -133,6 +134,7 @@ class VAEProgram:
         cfg = net.cfg
         self.net, self.B, self.L = net, B, L
         self.scaled = bool(cfg.stream_fp16_scaled)
+        self.fuse_gn_stats = bool(getattr(cfg, "fuse_gn_stats", True))
         dev = net.device
         self.arena = Arena(dev)
         self.em = Emitter(self.arena)
@@ -147,23 +149,39 @@ class VAEProgram:
 
     # ---- residual-stream format --------------------------------------------------------------
     # scaled (default): stream tensors hold value * 2^-4 in fp16;  f32: plain fp32 (see module docstring)
-    def _stream_conv(self, x, name, B, H, W, cin, cout, *, residual=None, out=None):
+    def _stats_for(self, out, B, H, W, cin_p, cout_p, ks=3):
+        """GroupNorm statistics from the producing conv's epilogue (LB_GEMM_CH_STATS): when the conv runs on the halo-tile
+        kernel, attach a statistics buffer to its output tensor; the GroupNorm that consumes the tensor then skips its
+        statistics pass (one read of the activation instead of two).  Returns the buffer or None."""
+        rows = self.em.halo_stat_rows(B, H, W, cin_p, cout_p, ks) if self.fuse_gn_stats else 0
+        if not rows:
+            return None
+        buf = self.arena.alloc((B * rows, cout_p, 2), F32)
+        out._lb_chstats = (buf, rows)
+        return buf
+
+    def _stream_conv(self, x, name, B, H, W, cin, cout, *, residual=None, out=None, stats=True):
         """3x3 conv whose output goes to the residual stream (or feeds only the next GroupNorm)."""
         w, sc = self.net.w, self.scaled
         cin_p, cout_p = _pad(cin, 8), _pad(cout, 4)
         if out is None:
             out = self.arena.alloc((B, H, W, cout_p), F16 if sc else F32)
         flags = 0 if sc else (lib.GEMM_OUT_F32 | (lib.GEMM_RES_F32 if residual is not None else 0))
+        st = self._stats_for(out, B, H, W, cin_p, cout_p) if stats else None
         self.em.gemm(x, w[name + ".weight"], out, M=B * H * W, bias=w[name + (".bias_s" if sc else ".bias")],
-                     residual=residual, flags=flags, alpha=STREAM_SCALE if sc else 1.0,
+                     residual=residual, flags=flags, alpha=STREAM_SCALE if sc else 1.0, ch_stats=st,
                      conv=dict(Hin=H, Win=W, Cin=cin_p, Hout=H, Wout=W, KH=3, KW=3, stride=1, pad=1, ups=0, ldx=cin_p))
         return out
 
     def _gn(self, x, out, name, B, HW, c, silu):
         w = self.net.w
         eps = 1e-6 * (STREAM_SCALE * STREAM_SCALE if self.scaled else 1.0)     # GroupNorm of a scaled tensor
+        st = getattr(x, "_lb_chstats", None)                                   # left by the conv that produced x?
         self.em.groupnorm(x, out, w[name + ".weight"], w[name + ".bias"], B=B, HW=HW, C_=c, eps=eps, silu=silu,
-                          groups=self.net.cfg.norm_groups)
+                          groups=self.net.cfg.norm_groups, ch_stats=st)
+        if st is not None:
+            self.arena.release(st[0])
+            x._lb_chstats = None
 
     def _stream_as_operand(self, x, B, H, W, c):
         """The raw stream as an fp16 MFMA operand carrying the 2^-4 scale: free in scaled mode, a
@@ -256,6 +274,7 @@ class VAEProgram:
                     em.gemm(h16, w[f"{name}.weight.sub4"][0], up, M=B * side * side,
                             bias=w[name + (".bias_s" if sc else ".bias")], ldc=c,
                             flags=0 if sc else lib.GEMM_OUT_F32, alpha=1.0 if sc else 1.0 / STREAM_SCALE,
+                            ch_stats=self._stats_for(up, B, side, side, c, c, ks=2),
                             conv=dict(Hin=side, Win=side, Cin=c, Hout=side, Wout=side, KH=2, KW=2, stride=1, pad=0,
                                       ups=0, ldx=c, parity="all"))
                 for py in (() if one else (0, 1)):           # else: four 2x2 convs on the low-res grid

@@ -707,3 +707,44 @@ def test_conv3x3_narrow_output(case, results_log):
     assert got.dtype == (torch.float32 if f32 else torch.float16)
     check_close(results_log, f"conv3x3_narrow_{'_'.join(map(str, case))}", got[..., :Cout], ref)
     assert float(got[..., Cout:].abs().max()) == 0 if cout_p > Cout else True
+
+
+@pytest.mark.parametrize("case", [(2, 32, 128, 128, False, False), (3, 16, 64, 320, True, False), (2, 32, 256, 128, False, True)])
+def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
+    """LB_GEMM_CH_STATS: the halo-tile conv's epilogue leaves, per (64-pixel row block, channel), (sum, sum of squares) of the
+    values it STORES (bias, alpha, residual included; fp16-rounded unless the output is fp32); lb_groupnorm_from_stats folds
+    them and applies GroupNorm (+SiLU) with ONE pass over the activation.  Checked: the raw statistics against torch on the
+    stored tensor, and the normalised output against the two-pass kernel and against torch GroupNorm."""
+    o, l = ops(), lib()
+    B, H, Cin, Cout, with_res, f32 = case
+    x = rnd(B, Cin, H, H, seed=211)
+    w = rnd(Cout, Cin, 3, 3, seed=212, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=213, dtype=torch.float32)
+    res = rnd(B, H, H, Cout, seed=214) if with_res else None
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = o.pack_conv_weight(w, Cin).to(DEV)
+    kind, tw, items, grid = o.conv_halo_plan(B, H, H, Cin, Cout)
+    assert kind == 3
+    rows = items // ((Cout + 127) // 128) // B * 4
+    st = torch.full((B * rows, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+    flags = l.GEMM_OUT_F32 if f32 else 0
+    l.api.lb_gemm_set_halo(2)
+    try:
+        y = o.gemm(xn, wp, bias=b.to(DEV), residual=None if res is None else res.to(DEV), flags=flags, alpha=0.5,
+                   conv=dict(KH=3, KW=3, stride=1, pad=1), ch_stats=st)
+        y_plain = o.gemm(xn, wp, bias=b.to(DEV), residual=None if res is None else res.to(DEV), flags=flags, alpha=0.5,
+                         conv=dict(KH=3, KW=3, stride=1, pad=1))
+    finally:
+        l.api.lb_gemm_set_halo(1)
+    assert torch.equal(y, y_plain), "the statistics epilogue must not change what the conv stores"
+    assert torch.isfinite(st).all(), "every (row block, channel) slot must be written"
+    yf = y.float().reshape(B, H * H, Cout)
+    tot = st.reshape(B, rows, Cout, 2).double().sum(dim=1).cpu()
+    want_s, want_q = yf.double().sum(dim=1).cpu(), (yf.double() ** 2).sum(dim=1).cpu()
+    assert torch.allclose(tot[..., 0], want_s, rtol=1e-4, atol=1e-2) and torch.allclose(tot[..., 1], want_q, rtol=1e-4, atol=1e-2)
+    gamma, beta = (1 + 0.1 * rnd(Cout, seed=215, dtype=torch.float32)).to(DEV), (0.1 * rnd(Cout, seed=216, dtype=torch.float32)).to(DEV)
+    got = o.groupnorm_from_stats(y, gamma, beta, 32, 1e-6, True, st, rows)
+    two_pass = o.groupnorm_nhwc(y, gamma, beta, 32, 1e-6, True)
+    ref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)).permute(0, 2, 3, 1)
+    check_close(results_log, f"groupnorm_from_conv_stats_{'_'.join(map(str, case))}", got, ref)
+    assert (got.float() - two_pass.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())

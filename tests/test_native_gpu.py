@@ -708,3 +708,34 @@ def test_wavefront_and_strided_slerp_beyond_32768_elements(results_log):
     d = np.stack([np.abs(np.asarray(x).astype(np.int32) - np.asarray(y).astype(np.int32)) for x, y in zip(i1, i4)])
     results_log["wavefront_L128"] = {"mean_abs_u8": float(d.mean())}
     assert d.mean() <= 1.0
+
+
+def test_dead_step_elision_is_bit_identical(results_log):
+    """BlendingEngine.elide_dead_steps (opt-in): with the SDXL-Turbo crossfeed defaults (1 / 1 / 1) the mid
+    branches' step at idx_injection is overwritten by the next step's crossfeed (coefficient exactly 1.0).  Skipping it must
+    leave every frame and every final latent bit-identical and the ancestral-noise stream aligned, with fewer UNet samples."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    set_backend(None)
+    _, p, tape = make_pair(turbo=True)
+
+    def run(elide):
+        np.random.seed(0)
+        be = BlendingEngine(p, verbose=False, frontier_width=8, do_compile=True)
+        be.elide_dead_steps = elide
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=7)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        tape.reset()
+        before = p.stats["unet_samples"]
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+        return be, [np.asarray(i) for i in imgs], p.stats["unet_samples"] - before, tape.draws
+    be_a, ia, n_a, d_a = run(False)
+    be_b, ib, n_b, d_b = run(True)
+    assert be_a.tree_fracts == be_b.tree_fracts and d_a == d_b
+    assert all(np.array_equal(x, y) for x, y in zip(ia, ib)), "frames must be bit-identical"
+    assert all(torch.equal(x[-1], y[-1]) for x, y in zip(be_a.tree_latents, be_b.tree_latents))
+    assert n_b == n_a - 7, (n_a, n_b)                      # one dead forward per mid branch
+    assert be_b.tree_latents[1][2] is None and be_a.tree_latents[1][2] is not None
+    results_log["dead_step_elision"] = {"unet_samples": [n_a, n_b]}
