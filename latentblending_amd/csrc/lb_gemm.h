@@ -88,6 +88,19 @@ template <int TM> struct LbLnRows { float mean[TM], rstd[TM]; };
 
 // RowFn: i -> global output row of the lane's i-th 16-row group (row0 + 16 i for the GEMM kernels; the pixel
 // index of a 2-D spatial tile for the halo conv kernel).
+// Sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane: two quad permutes, then
+// row_half_mirror and row_mirror - four v_add_f32 with a DPP operand, no LDS crossbar (the ds_bpermute form of __shfl_xor
+// made the statistics epilogue cost 5-12 % of a halo conv: profiles/r03_gn_stats_fusion.txt).
+__device__ __forceinline__ float lb_row16_sum(float v) {
+#define LB_DPP_ADD(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true))
+    LB_DPP_ADD(0xB1);       // quad_perm [1, 0, 3, 2]
+    LB_DPP_ADD(0x4E);       // quad_perm [2, 3, 0, 1]
+    LB_DPP_ADD(0x141);      // row_half_mirror
+    LB_DPP_ADD(0x140);      // row_mirror
+#undef LB_DPP_ADD
+    return v;
+}
+
 // CHST (LB_GEMM_CH_STATS, halo conv kernels): per output column, (sum, sum of squares) over the wave's 16 TM rows of the
 // values this epilogue STORES (after the fp16 rounding when the output is fp16) go to chst[n] (float2): each lane sums its
 // TM rows, the 16 lanes that share a column quad (l16 = 0..15) fold through wave shuffles in a fixed order, l16 == 0 writes.
@@ -238,12 +251,7 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             const int n = col0 + j * 16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float s = cs_s[j][r], q = cs_q[j][r];
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    s += __shfl_xor(s, d, LB_WAVE);
-                    q += __shfl_xor(q, d, LB_WAVE);
-                }
+                const float s = lb_row16_sum(cs_s[j][r]), q = lb_row16_sum(cs_q[j][r]);
                 if ((lane & 15) == 0 && n < p.N) chst[n + r] = make_float2(s, q);
             }
         }

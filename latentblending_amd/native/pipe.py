@@ -462,8 +462,13 @@ class StableDiffusionXLPipeline:
             if i < idx_injection or G == 0 or dead[i]:
                 prog, lat, params, n = prog_a, lat_a, par_a[i], A
                 noise = noise_a[i] if noise_a is not None else None
-                if dead[i] and i == idx_injection:      # (the next step's crossfeed replaces this value bit for bit)
-                    lat_m = torch.zeros((G,) + tuple(lat_a.shape[1:]), dtype=F16, device=self.device)
+                if dead[i] and i == idx_injection:
+                    # the mids' (never denoised) start value: the parental mix of step i-1, exactly what the live path starts
+                    # from - the next step's crossfeed slerp at coefficient 1.0 replaces it bit for bit, but its FIRST operand
+                    # must be a proper latent (a zero tensor has no direction: 0 / 0 in the slerp's cosine)
+                    lat_m = ops.slerp_strided(traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous(), fr_dev, n_lat,
+                                              broadcast0=True, broadcast1=True).view(G, *lat_a.shape[1:])
+                    self.stats["slerps"] += G
             else:
                 prev1, prev2 = traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous()
                 mix_prev = ops.slerp_strided(prev1, prev2, fr_dev, n_lat, broadcast0=True, broadcast1=True)   # parental mix of step i-1

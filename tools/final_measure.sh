@@ -5,7 +5,7 @@
 #   3. tools/pmc_summary.py folds them into profiles/<tag>_rocprof_summary.json  (bench.py reads roofline.traffic from it)
 #   4. the bench line itself, cfg 2 (+ the secondary lines: skewed metric, cfg 3)
 # Raw traces are dropped after summarising (gpurun merges at most 64 MiB back).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -27,9 +27,12 @@ for f in $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" -o -name "*domain_st
 find $OUT/${TAG}_stats $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -type f -size +2M -delete 2>/dev/null
 timeout 400 python bench.py $ARGS > $OUT/${TAG}_bench_1gpu.json 2> $OUT/${TAG}_bench_1gpu.err
 echo "bench rc=$?"; tail -c 600 $OUT/${TAG}_bench_1gpu.json | head -c 600; echo
-timeout 300 python bench.py --steps 6 --warmup 2 --metric-skew 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_skew3.json 2> $OUT/${TAG}_bench_skew3.err
-echo "skew rc=$?"
-timeout 400 python bench.py --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/${TAG}_bench_cfg3.json 2> $OUT/${TAG}_bench_cfg3.err
-echo "cfg3 rc=$?"
+# (the skewed-metric and cfg-3 lines are part of the bench line itself since round 3: "secondary")
+# rocprof-reported GB/s of the mixing / scheduler kernels on >= 1 GiB batches
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_mixing -- python $R/tools/mixing_rocprof.py run > $OUT/${TAG}_mixing.log 2>&1
+cd $R
+python tools/mixing_rocprof.py fold $OUT/${TAG}_mixing $OUT/${TAG}_mixing_rocprof.json > /dev/null 2>&1
+find $OUT/${TAG}_mixing -type f -size +2M -delete 2>/dev/null
 ls -la $OUT | head -40
 du -sh $OUT

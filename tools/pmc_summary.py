@@ -7,17 +7,17 @@ import glob
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"      # directory holding <tag>_stats/, <tag>_pmc_FETCH_SIZE/, <tag>_pmc_WRITE_SIZE/
 bench_args = sys.argv[3] if len(sys.argv) > 3 else "--steps 20 --warmup 5"
 
 
 def family(name):
-    if "gemm_f16" in name or "conv3x3_halo" in name:
+    if "gemm_f16" in name or "conv3x3_halo" in name or "conv3x3_narrow" in name:
         return "gemm"
     if "splitk_reduce" in name:
         return "gemm_splitk_reduce"
-    for k in ("attn_fwd", "layernorm", "gn_apply", "gn_partial", "cast_f32", "slerp", "lerp", "euler", "lpips", "softmax", "scale_input"):
+    for k in ("attn_fwd", "layernorm", "gn_apply", "gn_partial", "gn_fold", "cast_f32", "slerp", "lerp", "euler", "lpips", "softmax", "scale_input"):
         if k in name:
             return k
     return "other"
