@@ -88,22 +88,34 @@ template <int TM> struct LbLnRows { float mean[TM], rstd[TM]; };
 
 // RowFn: i -> global output row of the lane's i-th 16-row group (row0 + 16 i for the GEMM kernels; the pixel
 // index of a 2-D spatial tile for the halo conv kernel).
-// Sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane: two quad permutes, then
-// row_half_mirror and row_mirror - four v_add_f32 with a DPP operand, no LDS crossbar (the ds_bpermute form of __shfl_xor
-// made the statistics epilogue cost 5-12 % of a halo conv: profiles/r03_gn_stats_fusion.txt).
-__device__ __forceinline__ float lb_row16_sum(float v) {
-#define LB_DPP_ADD(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true))
-    LB_DPP_ADD(0xB1);       // quad_perm [1, 0, 3, 2]
-    LB_DPP_ADD(0x4E);       // quad_perm [2, 3, 0, 1]
-    LB_DPP_ADD(0x141);      // row_half_mirror
-    LB_DPP_ADD(0x140);      // row_mirror
-#undef LB_DPP_ADD
-    return v;
+// 32 values per lane -> their sums over the 16 lanes of a DPP row (lanes that share lane >> 4), two per lane, by a
+// halving butterfly: in each of four steps a lane keeps one half of its values, sends the other half to its partner and
+// adds what the partner sent - 16 + 8 + 4 + 2 exchanges instead of 32 x 4 for "reduce every value everywhere" (the
+// ds_bpermute form of __shfl_xor made this epilogue cost 5-12 % of a halo conv, the plain DPP form still ~5 %:
+// profiles/r03_gn_stats_fusion.txt).  Partners: lane ^ 1 and lane ^ 2 by quad permutes, then the neighbouring quad by
+// row_ror:4 (quads of opposite parity keep opposite halves, so the rotation delivers exactly the half its receiver
+// keeps; after it quads {0, 3} / {2, 1} are folded) and lane ^ 8 by row_ror:8.  With l = lane & 15 the lane ends up
+// holding values k = (l & 1) << 4 | (l >> 1 & 1) << 3 | (l >> 2 & 1) << 2 | (l >> 3) << 1 | {0, 1}.
+template <int CTRL> __device__ __forceinline__ float lb_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void lb_row16_reduce32(const float (&v)[32], float (&out)[2]) {
+    const int l = threadIdx.x & 15;
+    const bool b0 = l & 1, b1 = l & 2, b2 = l & 4, b3 = l & 8;
+    float w16[16], w8[8], w4[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w16[k] = (b0 ? v[k + 16] : v[k]) + lb_dpp_mov<0xB1>(b0 ? v[k] : v[k + 16]);      // quad_perm [1, 0, 3, 2]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w8[k] = (b1 ? w16[k + 8] : w16[k]) + lb_dpp_mov<0x4E>(b1 ? w16[k] : w16[k + 8]);   // quad_perm [2, 3, 0, 1]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = (b2 ? w8[k + 4] : w8[k]) + lb_dpp_mov<0x124>(b2 ? w8[k] : w8[k + 4]);      // row_ror:4
+#pragma unroll
+    for (int k = 0; k < 2; ++k) out[k] = (b3 ? w4[k + 2] : w4[k]) + lb_dpp_mov<0x128>(b3 ? w4[k] : w4[k + 2]);     // row_ror:8
 }
 
 // CHST (LB_GEMM_CH_STATS, halo conv kernels): per output column, (sum, sum of squares) over the wave's 16 TM rows of the
 // values this epilogue STORES (after the fp16 rounding when the output is fp16) go to chst[n] (float2): each lane sums its
-// TM rows, the 16 lanes that share a column quad (l16 = 0..15) fold through wave shuffles in a fixed order, l16 == 0 writes.
+// TM rows, the 16 lanes that share a column quad (l16 = 0..15) fold them with a DPP butterfly (fixed order), two values per lane.
 template <int TM, int TN, bool GEGLU, bool LNA, bool CHST = false, typename RowFn>
 __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
                                                            RowFn row_of, int col0, int gcol0, const LbLnRows<TM>* ln,
@@ -244,16 +256,24 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             lb_gemm_write4(p, crow, m, n, o);
         }
     }
-    if (CHST) {
-        const int lane = threadIdx.x & 63;
+    if constexpr (CHST) {
+        static_assert(TN == 4, "the channel-statistics epilogue folds 2 x 16 column values per lane");
+        float v[32], red[2];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = col0 + j * 16;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float s = lb_row16_sum(cs_s[j][r]), q = lb_row16_sum(cs_q[j][r]);
-                if ((lane & 15) == 0 && n < p.N) chst[n + r] = make_float2(s, q);
+                v[j * 4 + r] = cs_s[j][r];
+                v[16 + j * 4 + r] = cs_q[j][r];
             }
+        lb_row16_reduce32(v, red);
+        const int l = threadIdx.x & 15;
+        const int which = l & 1, j = ((l >> 1) & 1) * 2 + ((l >> 2) & 1), r0 = (l >> 3) * 2;     // the two values this lane holds
+        const int n = col0 + j * 16 + r0;
+        if (n < p.N) {          // (N % 4 == 0: columns n and n + 1 are valid together)
+            float* f = reinterpret_cast<float*>(chst);
+            f[2 * n + which] = red[0];
+            f[2 * n + 2 + which] = red[1];
         }
     }
 }
