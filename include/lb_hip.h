@@ -147,6 +147,7 @@ void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long*
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
+void lb_gemm_set_wide_store(int on);              /* tuning: 1 = 16-byte epilogue stores for fp16 row-major outputs (same results) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached

@@ -426,8 +426,10 @@ int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream) {
     return lb_conv3x3_halo_eligible(p) == 32 ? launch_halo<128, 32>(p, stream) : launch_halo<128, 16>(p, stream);
 }
 
+extern int g_lb_wide_store;
 extern "C" int lb_conv3x3_halo_f16(const LbGemmParams* pp, void* stream) {
     LbGemmParams p = *pp;
+    p.reserved2_ = g_lb_wide_store & 1;
     LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_conv3x3_halo_f16: empty problem");
     LB_REQUIRE(lb_conv3x3_halo_eligible(p) != 0,
                "lb_conv3x3_halo_f16: needs a 3x3 / stride 1 / pad 1 conv, Cin % 64 == 0, W % 16 == 0, zero page");

@@ -353,6 +353,10 @@ extern "C" void lb_gemm_set_variant(int variant, int stages) {   // variant < 0:
     if (variant == 1) lb_gemm_glds_init();
 }
 
+// 1 (default) = fp16 row-major epilogues store 16 B per lane (column-group pairs exchanged through v_permlane16_swap); 0 = 8-B stores
+int g_lb_wide_store = 1;     // measured: VAE decode B=17 45.9 -> 44.8 ms, UNet B=17 38.11 -> 37.69 ms, bit-identical (profiles/r03_wide_store_ab.txt)
+extern "C" void lb_gemm_set_wide_store(int on) { g_lb_wide_store = on; }
+
 extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     // enough for the largest split the heuristic can pick (<= 16 slabs)
     return (long)16 * M * N * (long)sizeof(float);
@@ -521,6 +525,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(p.lda >= p.K && !(p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: LB_GEMM_LN_A normalises whole rows of A");
     }
     if (p.alpha == 0.f) p.alpha = 1.f;
+    p.reserved2_ = g_lb_wide_store & 1;
     if (p.scatter == 2) {       // all four sub-pixel parities in one launch: only the halo kernel implements it
         LB_REQUIRE(lb_upconv_halo_eligible(p) != 0, "lb_gemm_f16: scatter = 2 needs Cin % 64 == 0, W % 16 == 0, stacked [4][N][K] weights");
         LB_DISPATCH("lb_upconv2x_halo_f16", lb_upconv_halo_launch(p, s));

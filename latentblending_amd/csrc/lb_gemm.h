@@ -3,6 +3,8 @@
 #include "lb_common.h"
 #include "../../include/lb_hip.h"
 
+typedef _Float16 lb_h2x __attribute__((ext_vector_type(2)));
+
 // v = 4 consecutive output columns n..n+3 of row m (fp32 accumulators).
 __device__ __forceinline__ void lb_gemm_store4(const LbGemmParams& p, int m, int n, int bidx, f32x4 v) {
     float o[4];
@@ -132,14 +134,19 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             bh[jp] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : zero4;
             bg[jp] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + half + nc) : zero4;
         }
+        // WIDE stores (see below): output column groups jp and jp + 1 paired through v_permlane16_swap -> 16-byte stores
+        const bool gwide = TP % 2 == 0 && (p.reserved2_ & 1) && (p.ldc & 7) == 0 &&
+                           (gcol0 - 4 * ((threadIdx.x & 63) >> 4)) + 16 * TP <= half;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = row_of(i);
-            if (m >= p.M) continue;
+            if (!gwide && m >= p.M) continue;
+            const bool m_ok = m < p.M;
+            unsigned glo[2] = {0u, 0u};
 #pragma unroll
             for (int jp = 0; jp < TP; ++jp) {
                 const int n = gcol0 + jp * 16;
-                if (n >= half) continue;
+                if (!gwide && n >= half) continue;
                 f32x4 ch = zero4, cg = zero4;       // (LN_A column sums: re-read per row, L1 hits, no registers held)
                 if (LNA) {
                     ch = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
@@ -156,6 +163,22 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
                     const float h = ah * p.alpha + bh[jp][r];
                     const float gt = ag * p.alpha + bg[jp][r];
                     o[r] = (f16)(h * lb_gelu_erf(gt));
+                }
+                if (gwide) {
+                    const unsigned u0 = __builtin_bit_cast(unsigned, (lb_h2x){o[0], o[1]}), u1 = __builtin_bit_cast(unsigned, (lb_h2x){o[2], o[3]});
+                    if ((jp & 1) == 0) {
+                        glo[0] = u0;
+                        glo[1] = u1;
+                    } else {
+                        const auto r0 = __builtin_amdgcn_permlane16_swap(glo[0], u0, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane16_swap(glo[1], u1, false, false);
+                        const int nst = (((threadIdx.x & 63) >> 4) & 1) ? n - 4 : n - 16;
+                        if (m_ok) {
+                            typedef unsigned lb_u4g __attribute__((ext_vector_type(4)));
+                            *reinterpret_cast<lb_u4g*>((f16*)p.C + (long)m * p.ldc + nst) = (lb_u4g){r0[0], r1[0], r0[1], r1[1]};
+                        }
+                    }
+                    continue;
                 }
                 *reinterpret_cast<f16x4*>((f16*)p.C + (long)m * p.ldc + n) = o;
             }
@@ -216,6 +239,12 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             const int y = rem / p.Wout, x = rem - y * p.Wout;
             crow = ((long)b * 2 * p.Hout + 2 * y + p.sc_py) * (2 * p.Wout) + 2 * x + p.sc_px;
         }
+        // WIDE stores (p.reserved2_ & 1, fp16 row-major outputs whose wave column range is entirely inside N): the lane's
+        // quads of column groups j and j + 1 are paired with the neighbouring 16-lane row through v_permlane16_swap, so
+        // that every lane owns 8 CONSECUTIVE halves - 16-byte stores, half as many store instructions per tile.
+        const bool wide = TN % 2 == 0 && (p.reserved2_ & 1) && !(p.flags & (LB_GEMM_TRANS_OUT | LB_GEMM_OUT_F32)) &&
+                          (p.ldc & 7) == 0 && (col0 - 4 * ((threadIdx.x & 63) >> 4)) + 16 * TN <= p.N;
+        unsigned wide_lo[2] = {0u, 0u};
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = col0 + j * 16;
@@ -223,7 +252,7 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             // "pending" in the compiler's wait bookkeeping, and a kernel that calls this epilogue inside a loop - the
             // persistent halo conv - then gets a compiler-inserted vmcnt(0) at the head of its MFMA loop)
             asm volatile("" ::"v"(add[j]));
-            if (!m_ok || n >= p.N) continue;
+            if (!wide && (!m_ok || n >= p.N)) continue;
             float o[4];
             f32x4 cs = zero4;
             if (LNA) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
@@ -252,6 +281,26 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
                     cs_s[j][r] += h;
                     cs_q[j][r] += h * h;
                 }
+            }
+            if (wide) {
+                const f16x4 h4 = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+                const unsigned u0 = __builtin_bit_cast(unsigned, (lb_h2x){h4[0], h4[1]}), u1 = __builtin_bit_cast(unsigned, (lb_h2x){h4[2], h4[3]});
+                if ((j & 1) == 0) {
+                    wide_lo[0] = u0;
+                    wide_lo[1] = u1;
+                } else {
+                    // swap odd rows (g odd) of the (j-1) quad with even rows of the j quad: even g ends with columns
+                    // 16 (j-1) + 4 g .. + 7, odd g with columns 16 j + 4 (g-1) .. + 7
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(wide_lo[0], u0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(wide_lo[1], u1, false, false);
+                    const int g_ = (threadIdx.x & 63) >> 4;
+                    const int nst = (g_ & 1) ? n - 4 : n - 16;
+                    if (m_ok) {
+                        typedef unsigned lb_u4 __attribute__((ext_vector_type(4)));
+                        *reinterpret_cast<lb_u4*>((f16*)p.C + crow * p.ldc + nst) = (lb_u4){r0[0], r1[0], r0[1], r1[1]};
+                    }
+                }
+                continue;
             }
             lb_gemm_write4(p, crow, m, n, o);
         }
