@@ -30,6 +30,9 @@
 // Round 2: PERSISTENT blocks (one per CU walks items bid, bid + G, ...) whose request streams run across tile
 // boundaries (see the kernel).  profiles/r02_halo_study.txt splits a tile's time: MFMA + LDS alone run at 640-680 ns per
 // step (427 ns at the MFMA peak); activation reads add ~2 us per 64-channel chunk and the epilogue 4-6 us per tile.
+// Round 3: a third follow-up of the same kind - extra vmcnt slack (+8 / +16) in the first three steps of a tile, so that
+// they do not wait for the previous tile's epilogue stores (vmcnt retires in order): bit-identical, -0.2 % on the VAE decode
+// batch, nothing on the UNet (profiles/r03_halo_store_slack_ab.txt) - the tile-boundary cost is not the store drain either.
 // Two follow-ups were built, verified bit-for-bit and measured, and are NOT in this file (git history has them):
 //   * separate loader roles (4 halo waves + 4 weight waves, so that an HBM-latency halo request never sits in front of the
 //     L2-latency weight requests in a wave's in-order vmcnt): +3-8 % on the VAE shapes in isolation, -5 % on the UNet's

@@ -9,6 +9,7 @@ import latentblending_amd.native as N
 from latentblending_amd.hip import lib
 
 DEV = "cuda:0"
+MODES = tuple(int(v) for v in os.environ.get("LB_AB_MODES", "0,1").split(","))   # lb_gemm_set_wide_store values: bit 0 wide stores, bit 1 = no tile-boundary store slack
 
 
 def timed(launch, iters):
@@ -29,7 +30,7 @@ def main():
     vae = N.NativeVAEDecoder(N.VAEConfig(), N.SyntheticProvider(1), DEV)
     outs = {}
     for rep in range(2):
-        for wide in (0, 1):
+        for wide in MODES:
             lib.api.lb_gemm_set_wide_store(wide)
             prog = vae.build(17, 64)                      # (the flag is read when the program is RECORDED)
             prog.decode(z)
@@ -38,7 +39,7 @@ def main():
             outs[wide] = prog.decode(z).clone()
             print(f"VAE decode B=17: wide_store={wide}: {ms:7.3f} ms", flush=True)
             del prog
-    print("VAE frames identical:", bool(torch.equal(outs[0], outs[1])))
+    print("VAE frames identical:", bool(torch.equal(outs[MODES[0]], outs[MODES[1]])))
     if "--unet" in sys.argv:
         cdir = os.environ.get("LB_SYNTH_CACHE")
         prov = N.SyntheticProvider(0, cache_file=os.path.join(cdir, "lb_synth_seed0.pt") if cdir else None)
@@ -51,7 +52,7 @@ def main():
             x = torch.randn(B, 4, 64, 64, generator=g).half().to(DEV)
             res = {}
             for rep in range(2):
-                for wide in (0, 1):
+                for wide in MODES:
                     lib.api.lb_gemm_set_wide_store(wide)
                     prog = net.build(B, 64)
                     prog.set_conditioning(ctx, te, ids)
@@ -61,8 +62,8 @@ def main():
                     res[wide] = prog.forward(x, torch.full((B,), 499.0)).clone()
                     print(f"UNet step B={B}: wide_store={wide}: {ms:7.3f} ms", flush=True)
                     del prog
-            print(f"UNet B={B} outputs identical:", bool(torch.equal(res[0], res[1])))
-    lib.api.lb_gemm_set_wide_store(0)
+            print(f"UNet B={B} outputs identical:", bool(torch.equal(res[MODES[0]], res[MODES[1]])))
+    lib.api.lb_gemm_set_wide_store(1)
 
 
 if __name__ == "__main__":
