@@ -12,11 +12,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export LB_SYNTH_CACHE=/tmp          # seeded synthetic weights: generated once, the later processes load them
 ARGS="--steps 20 --warmup 5"
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $R/bench.py $ARGS --no-cpu-baseline --no-roofline > $OUT/${TAG}_stats.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python $R/bench.py $ARGS --no-cpu-baseline --no-roofline --no-secondary > $OUT/${TAG}_stats.log 2>&1
 echo "stats rc=$?"
 PARGS="--steps 4 --warmup 1"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python $R/bench.py $PARGS --no-graphs --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_$C.log 2>&1
+  timeout 400 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python $R/bench.py $PARGS --no-graphs --no-cpu-baseline --no-roofline --no-secondary > $OUT/${TAG}_pmc_$C.log 2>&1
   echo "pmc $C rc=$?"
 done
 cd $R

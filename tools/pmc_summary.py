@@ -35,7 +35,7 @@ if stats:
     total = sum(v[0] for v in fam.values())
     out["kernel_time_by_family"] = {k: {"total_ms": v[0] / 1e6, "calls": v[1], "avg_us": v[0] / v[1] / 1e3,
                                         "share": v[0] / total} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
-    out["kernel_stats_command"] = f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py {bench_args} --no-cpu-baseline --no-roofline"
+    out["kernel_stats_command"] = f"rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py {bench_args} --no-cpu-baseline --no-roofline --no-secondary"
 pmc = {}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(f"{src}/{tag}_pmc_{counter}/**/*counter_collection.csv", recursive=True)
@@ -55,7 +55,7 @@ if len(pmc) == 2:
     out["gemm_family_hbm_traffic"] = {"launches": n, "fetch_bytes_corrected": fetch, "write_bytes": write,
                                       "bytes_per_launch": (fetch + write) / n,
                                       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
-                                              f"`bench.py {bench_args} --no-graphs --no-cpu-baseline --no-roofline`; FETCH x2 correction "
+                                              f"`bench.py {bench_args} --no-graphs --no-cpu-baseline --no-roofline --no-secondary`; FETCH x2 correction "
                                               "(MI355X_MICROARCH.md §HBM); Infinity-Cache hits are counted; GEMM family = "
                                               "gemm_f16_* + conv3x3_halo_kernel launches"}
 json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)
