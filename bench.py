@@ -409,6 +409,7 @@ def secondary_lines(pipe, args, branches):
 
     try:
         be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+        be.host_frames = True
         be.pair_metric = skewed_metric(be, 3.0)
         be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
         be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
@@ -423,6 +424,7 @@ def secondary_lines(pipe, args, branches):
     try:    # opt-in engine feature, NOT the metric: the reference performs these forwards, so the headline does too
         be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
         be.elide_dead_steps = True
+        be.host_frames = True
         be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
         be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
         be.set_branching(nmb_max_branches=branches)
@@ -437,6 +439,7 @@ def secondary_lines(pipe, args, branches):
         base_pipe = N.NativeSDXLPipe(turbo=False, unet_native=pipe.unet_native, vae_native=pipe.vae_native, device=str(pipe.device),
                                      allow_synthetic=True)
         be = BlendingEngine(base_pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+        be.host_frames = True
         be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
         be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
         be.set_branching(depth_strength=0.5, nmb_max_branches=15)
@@ -523,6 +526,7 @@ def _run():
         branches, scaling = args.branches, "strong"
     be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier * (world if scaling == "weak" else 1),
                         verbose=False, farm=farm)
+    be.host_frames = not args.no_materialise     # the metric's frames are host PIL images, as the reference returns them
     if args.metric_skew:
         be.pair_metric = skewed_metric(be, args.metric_skew)
     be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")

@@ -77,6 +77,9 @@ class BlendingEngine:
         #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
+        self.host_frames = False            # True: run_transition hands back HOST PIL images (the reference's return type in full) -
+        #                                     their device->host copy and PIL construction overlap the tail of the VAE decode on a
+        #                                     native pipe; False (default): lazy DeviceImage frames, copied when first touched
         self.elide_dead_steps = False       # opt-in (native fused wavefront): skip mid steps the next step's crossfeed (coefficient
         #                                     exactly 1.0, the Turbo defaults) overwrites completely - bit-identical frames, fewer
         #                                     UNet forwards than the reference performs; tree_latents entries of the
@@ -292,7 +295,11 @@ class BlendingEngine:
             else:
                 first = self.tree_latents[0] if keep1 else self.compute_latents1()
                 last = self.tree_latents[-1] if keep2 else self.compute_latents2()
-            return self._grow_tree(first, last, prefilled, use_frontier)
+            frames = self._grow_tree(first, last, prefilled, use_frontier)
+            if self.host_frames and _is_native(self.dh.pipe):
+                from .native.frames import materialise_frames
+                materialise_frames(frames)              # whatever the decode batches left lazy
+            return frames
         finally:
             if restore_noise is not None:
                 restore_noise()
@@ -487,9 +494,9 @@ class BlendingEngine:
         if farm and farm.rank != 0:
             # the anchors' FRAMES come from rank 0 in the broadcast below: only their owner decodes them (at 8 ranks the
             # decode batch of a non-owner halves: 2 mid frames instead of 2 + 2)
-            frames = [None, None] + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])
+            frames = [None, None] + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil", host=self.host_frames) if mids else [])
         else:
-            frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
+            frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil", host=self.host_frames)
         if farm:    # C1: rank 0's anchors (stacks + frames) become everybody's - bit-identical parents / end frames on all ranks
             (first, last), anchor_frames = farm.share_anchor_pair([first, last], frames[:2], 0, steps, self._frame_from_u8,
                                                                   self._latent_chw(), (self.dh.height_img, self.dh.width_img))
@@ -651,7 +658,7 @@ class BlendingEngine:
                 num_inference_steps=self.num_inference_steps,
                 guidance_scales=[s["guidance"] for s in sel],
                 noise_slots=None if only is None else (len(specs), chosen))
-            frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil")
+            frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil", host=self.host_frames)
             return list(zip(trajs, frames))
         out = []
         for k, s in enumerate(specs):

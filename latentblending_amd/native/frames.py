@@ -49,6 +49,11 @@ class DeviceImage(Image.Image):
 
 _PINNED: dict = {}
 
+def host_cores(host_u8) -> list:
+    """PIL pixel cores of host uint8 frames [n, H, W, 3]: PIL unpacks RGB into its own RGBX storage - ONE host copy per frame
+    (so the source buffer is free again afterwards).  (A thread pool was measured slower: the unpack holds the GIL.)"""
+    return [Image.fromarray(arr, "RGB").im for arr in host_u8]
+
 
 def materialise_frames(frames) -> int:
     """Bring every still device-resident ``DeviceImage`` of ``frames`` to the host in ONE device->host copy (one stream
@@ -66,9 +71,10 @@ def materialise_frames(frames) -> int:
             pinned = _PINNED[key] = torch.empty(stacked.shape, dtype=torch.uint8, pin_memory=True)
         pinned.copy_(stacked, non_blocking=True)
         torch.cuda.current_stream(stacked.device).synchronize()
-        host = pinned.numpy().copy()                      # (the PIL cores own their pixels: the staging buffer is reused)
-        for f, arr in zip(dev, host):
-            f._im = Image.fromarray(np.ascontiguousarray(arr), "RGB").im
+        host = pinned.numpy()
+        cores = host_cores(host)
+        for f, core in zip(dev, cores):
+            f._im = core
             f._lb_loaded = True
     for f in todo:
         f._materialise()

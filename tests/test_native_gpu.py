@@ -739,3 +739,36 @@ def test_dead_step_elision_is_bit_identical(results_log):
     assert n_b == n_a - 7, (n_a, n_b)                      # one dead forward per mid branch
     assert be_b.tree_latents[1][2] is None and be_a.tree_latents[1][2] is not None
     results_log["dead_step_elision"] = {"unet_samples": [n_a, n_b]}
+
+
+def test_host_frames_are_built_behind_the_decode(results_log):
+    """BlendingEngine.host_frames: run_transition hands back HOST PIL images (pixels copied, PIL cores built) - the first
+    three quarters of a decode batch cross PCIe and are built while the GPU decodes the rest.  Same tree, frames within the
+    batch-shape tolerance of the lazy mode (two decode programs instead of one), every frame loaded on return."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.native.frames import DeviceImage
+    set_backend(None)
+    _, p, tape = make_pair(turbo=True)
+
+    def run(host):
+        np.random.seed(0)
+        be = BlendingEngine(p, verbose=False, frontier_width=16, do_compile=True)
+        be.host_frames = host
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=9)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        tape.reset()
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+        loaded = [bool(getattr(i, "_lb_loaded", True)) for i in imgs]
+        return be, imgs, loaded
+    be_l, il, loaded_l = run(False)
+    be_h, ih, loaded_h = run(True)
+    assert not any(loaded_l) and all(isinstance(i, DeviceImage) for i in il), "default: frames stay in HBM until touched"
+    assert all(loaded_h) and len(ih) == 11
+    assert be_l.tree_fracts == be_h.tree_fracts
+    d = np.stack([np.abs(np.asarray(a).astype(np.int32) - np.asarray(b).astype(np.int32)) for a, b in zip(il, ih)])
+    results_log["host_frames"] = {"mean_abs_u8": float(d.mean()), "max_abs_u8": int(d.max())}
+    assert d.mean() <= 0.5 and d.max() <= 8
+    assert ih[3].size == (128, 128) and ih[3].mode == "RGB"
