@@ -78,8 +78,8 @@ class BlendingEngine:
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
         self.host_frames = False            # True: run_transition hands back HOST PIL images (the reference's return type in full) -
-        #                                     their device->host copy and PIL construction overlap the tail of the VAE decode on a
-        #                                     native pipe; False (default): lazy DeviceImage frames, copied when first touched
+        #                                     their device->host copy runs on a side stream and their PIL cores are built while the GPU
+        #                                     computes the LPIPS distances (native pipe); False (default): lazy DeviceImage frames, copied when first touched
         self.elide_dead_steps = False       # opt-in (native fused wavefront): skip mid steps the next step's crossfeed (coefficient
         #                                     exactly 1.0, the Turbo defaults) overwrites completely - bit-identical frames, fewer
         #                                     UNet forwards than the reference performs; tree_latents entries of the
@@ -298,7 +298,8 @@ class BlendingEngine:
             frames = self._grow_tree(first, last, prefilled, use_frontier)
             if self.host_frames and _is_native(self.dh.pipe):
                 from .native.frames import materialise_frames
-                materialise_frames(frames)              # whatever the decode batches left lazy
+                self.dh.pipe.finish_host_frames()
+                materialise_frames(frames)              # (frames that came from elsewhere: exchanged between ranks, recycled)
             return frames
         finally:
             if restore_noise is not None:

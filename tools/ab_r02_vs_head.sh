@@ -6,7 +6,7 @@ R=$PWD
 export LB_SYNTH_CACHE=/tmp
 (cd $R/_ab_r02 && python __graft_entry__.py > /tmp/ab_build.log 2>&1; tail -1 /tmp/ab_build.log)
 val() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print('%.2f frames/s  %.2f ms' % (d['value'], d['ms_per_step']))" $1; }
-for rep in 1 2; do
+for rep in $(seq 1 ${LB_AB_REPS:-2}); do
   (cd $R/_ab_r02 && timeout 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline > /tmp/ab_r02.json 2>/dev/null)
   echo "rep $rep  round-2 tree (frames left in HBM)            : $(val /tmp/ab_r02.json)"
   (cd $R && timeout 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-roofline --no-secondary --no-materialise > /tmp/ab_head_nomat.json 2>/dev/null)
