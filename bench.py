@@ -526,7 +526,7 @@ def _run():
         branches, scaling = args.branches, "strong"
     be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier * (world if scaling == "weak" else 1),
                         verbose=False, farm=farm)
-    be.host_frames = not args.no_materialise     # the metric's frames are host PIL images, as the reference returns them
+    be.host_frames = not args.no_materialise   # the metric's frames are host PIL images, as the reference returns them
     if args.metric_skew:
         be.pair_metric = skewed_metric(be, args.metric_skew)
     be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")

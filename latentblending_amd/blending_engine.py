@@ -77,9 +77,12 @@ class BlendingEngine:
         #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
-        self.host_frames = False            # True: run_transition hands back HOST PIL images (the reference's return type in full) -
-        #                                     their device->host copy runs on a side stream and their PIL cores are built while the GPU
-        #                                     computes the LPIPS distances (native pipe); False (default): lazy DeviceImage frames, copied when first touched
+        self.host_frames = False            # True: run_transition hands back HOST PIL images (the reference's return type in full): one
+        #                                     device->host copy of all frames through a pinned buffer + their PIL cores, ~1.6 ms per
+        #                                     17-frame transition; False (default): lazy DeviceImage frames, copied when first touched.
+        #                                     (Two overlapped forms - decode as 3/4 + 1/4 batches, or copy on a side stream and build
+        #                                     behind the LPIPS kernels - both measured SLOWER than the plain copy at the end:
+        #                                     profiles/r03_materialise_ab.txt)
         self.elide_dead_steps = False       # opt-in (native fused wavefront): skip mid steps the next step's crossfeed (coefficient
         #                                     exactly 1.0, the Turbo defaults) overwrites completely - bit-identical frames, fewer
         #                                     UNet forwards than the reference performs; tree_latents entries of the
@@ -298,8 +301,7 @@ class BlendingEngine:
             frames = self._grow_tree(first, last, prefilled, use_frontier)
             if self.host_frames and _is_native(self.dh.pipe):
                 from .native.frames import materialise_frames
-                self.dh.pipe.finish_host_frames()
-                materialise_frames(frames)              # (frames that came from elsewhere: exchanged between ranks, recycled)
+                materialise_frames(frames)              # ONE device->host copy of the whole transition + the PIL pixel cores
             return frames
         finally:
             if restore_noise is not None:
@@ -495,9 +497,9 @@ class BlendingEngine:
         if farm and farm.rank != 0:
             # the anchors' FRAMES come from rank 0 in the broadcast below: only their owner decodes them (at 8 ranks the
             # decode batch of a non-owner halves: 2 mid frames instead of 2 + 2)
-            frames = [None, None] + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil", host=self.host_frames) if mids else [])
+            frames = [None, None] + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])
         else:
-            frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil", host=self.host_frames)
+            frames = pipe.native_latent2image_batch([first[-1], last[-1]] + [t[-1] for t in mids], "pil")
         if farm:    # C1: rank 0's anchors (stacks + frames) become everybody's - bit-identical parents / end frames on all ranks
             (first, last), anchor_frames = farm.share_anchor_pair([first, last], frames[:2], 0, steps, self._frame_from_u8,
                                                                   self._latent_chw(), (self.dh.height_img, self.dh.width_img))
@@ -659,7 +661,7 @@ class BlendingEngine:
                 num_inference_steps=self.num_inference_steps,
                 guidance_scales=[s["guidance"] for s in sel],
                 noise_slots=None if only is None else (len(specs), chosen))
-            frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil", host=self.host_frames)
+            frames = pipe.native_latent2image_batch([t[-1] for t in trajs], "pil")
             return list(zip(trajs, frames))
         out = []
         for k, s in enumerate(specs):

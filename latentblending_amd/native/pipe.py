@@ -153,9 +153,6 @@ class StableDiffusionXLPipeline:
         self._embed_cache: OrderedDict = OrderedDict()           # text -> (prompt_embeds, pooled); cleared when the encoder changes
         self._use_graphs = False
         self._feat_scratch: Dict[int, list] = {}
-        self._pending_host: list = []
-        self._host_pool: list = []
-        self._copy_stream = None
         self.stats = {"unet_forwards": 0, "unet_samples": 0, "vae_decodes": 0, "slerps": 0, "lpips_pairs": 0}
 
     def _synthetic_notice(self, what: str, how: str):
@@ -506,13 +503,8 @@ class StableDiffusionXLPipeline:
         return traj_a[0], traj_a[1], traj_m
 
     @torch.no_grad()
-    def native_latent2image_batch(self, latents: Sequence[torch.Tensor], output_type="pil", host: bool = False):
-        """``host``: the caller wants HOST images in the end (what the reference's run_transition hands back): see
-        ``_decode_with_async_host_copy`` / ``finish_host_frames``.  (Decoding the batch as 3/4 + 1/4 programs and building the
-        first part's frames behind the second part was measured too: the split costs the GPU what the overlap saves.)"""
+    def native_latent2image_batch(self, latents: Sequence[torch.Tensor], output_type="pil"):
         z = torch.cat([t.to(self.device, F16).reshape(1, -1, t.shape[-2], t.shape[-1]) for t in latents])
-        if host and output_type == "pil":
-            return self._decode_with_async_host_copy(z)
         prog = self.vae_program(z.shape[0], z.shape[-1])
         frames = prog.decode(z).clone()
         self.stats["vae_decodes"] += z.shape[0]
@@ -520,45 +512,6 @@ class StableDiffusionXLPipeline:
             img = (prog.image_f32[..., :3].float() / 2 + 0.5).clamp(0, 1)
             return [f.cpu().numpy() for f in img]
         return [DeviceImage(f) for f in frames]
-
-    def _decode_with_async_host_copy(self, z: torch.Tensor):
-        """Decode batch whose frames must end up as HOST PIL images: the uint8 frames cross PCIe on a side stream as soon as
-        the decode program has finished, and their PIL cores are built by ``finish_host_frames`` - which the engine's next
-        step (``native_frame_distances``) calls AFTER it has queued the LPIPS kernels, i.e. while the GPU is still busy."""
-        from .frames import DeviceImage as DI
-        prog = self.vae_program(z.shape[0], z.shape[-1])
-        frames = prog.decode(z).clone()
-        self.stats["vae_decodes"] += z.shape[0]
-        main = torch.cuda.current_stream(self.device)
-        if getattr(self, "_copy_stream", None) is None:
-            self._copy_stream = torch.cuda.Stream(device=self.device)
-        decoded = torch.cuda.Event()
-        decoded.record(main)
-        pinned = torch.empty(tuple(frames.shape), dtype=torch.uint8, pin_memory=True) if not self._host_pool else self._host_pool.pop()
-        if tuple(pinned.shape) != tuple(frames.shape):
-            pinned = torch.empty(tuple(frames.shape), dtype=torch.uint8, pin_memory=True)
-        copied = torch.cuda.Event()
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(decoded)
-            frames.record_stream(self._copy_stream)
-            pinned.copy_(frames, non_blocking=True)
-            copied.record(self._copy_stream)
-        imgs = [DI(f) for f in frames]
-        self._pending_host.append((copied, pinned, imgs))
-        return imgs
-
-    def finish_host_frames(self):
-        """Build the PIL cores of every decode batch whose pixels are on their way to (or already in) host memory."""
-        from .frames import host_cores
-        while self._pending_host:
-            copied, pinned, imgs = self._pending_host.pop(0)
-            copied.synchronize()
-            for img, core in zip(imgs, host_cores(pinned.numpy())):
-                if not img._lb_loaded:
-                    img._im = core
-                    img._lb_loaded = True
-            if len(self._host_pool) < 2:
-                self._host_pool.append(pinned)              # (page-locked staging buffers are reused: PIL copied the pixels)
 
     def native_latent2image(self, latents, output_type="pil"):
         return self.native_latent2image_batch([latents], output_type)[0]
@@ -586,7 +539,6 @@ class StableDiffusionXLPipeline:
                 self._feat_scratch[id(f)] = feats
         feat_of = lambda f: getattr(f, "_lb_feats", None) or self._feat_scratch[id(f)]
         d = self.lpips_metric.distances([(feat_of(a), feat_of(b)) for a, b in pairs])
-        self.finish_host_frames()       # (the LPIPS kernels are queued: build pending host frames while the GPU works on them)
         self.stats["lpips_pairs"] += len(pairs)
         self._feat_scratch.clear()
         return [float(v) for v in d.tolist()]

@@ -741,10 +741,9 @@ def test_dead_step_elision_is_bit_identical(results_log):
     results_log["dead_step_elision"] = {"unet_samples": [n_a, n_b]}
 
 
-def test_host_frames_are_built_behind_the_decode(results_log):
-    """BlendingEngine.host_frames: run_transition hands back HOST PIL images (pixels copied on a side stream right after the
-    decode, PIL cores built while the GPU computes the LPIPS distances).  Same tree and the very same pixels as the lazy
-    mode, every frame loaded on return."""
+def test_host_frames_mode(results_log):
+    """BlendingEngine.host_frames: run_transition hands back HOST PIL images (one device->host copy of all frames, PIL cores
+    built).  Same tree and the very same pixels as the lazy mode, every frame loaded on return."""
     from latentblending_amd import BlendingEngine
     from latentblending_amd.backend import set_backend
     from latentblending_amd.native.frames import DeviceImage
