@@ -80,7 +80,7 @@ enum {
     LB_GEMM_GELU = 256,      /* erf GELU after bias (OpenCLIP bigG MLP) */
     LB_GEMM_CH_STATS = 512,  /* halo-tile convs only (lb_conv3x3_halo_f16 / lb_upconv2x_halo_f16, also when lb_gemm_f16 routes
                               * there): besides C, write per (64-pixel row block, output channel) the (sum, sum of squares) of
-                              * the STORED values to ch_stats[row block][N] (float2) - the GroupNorm statistics of this conv's
+                              * the STORED values to ch_stats[channel][row block] (float2, channel-major) - the GroupNorm statistics of this conv's
                               * output without a second pass over it (lb_groupnorm_from_stats).  Row block = (tile [, parity])
                               * * 4 + wave row: lb_conv_halo_plan reports items; rows per sample = items / channel blocks / B * 4 */
     LB_GEMM_LN_A = 64        /* A is consumed through a LayerNorm over its K columns (K = the normalised width):
@@ -121,7 +121,7 @@ typedef struct LbGemmParams {
     const float* ln_colsum;  /* LB_GEMM_LN_A: [N] fp32 column sums of W' */
     float ln_eps;            /* LB_GEMM_LN_A: LayerNorm epsilon */
     int reserved2_;
-    float* ch_stats;         /* LB_GEMM_CH_STATS: output [row blocks][N] float2 (sum, sum of squares), else unused */
+    float* ch_stats;         /* LB_GEMM_CH_STATS: output [N][row blocks] float2 (sum, sum of squares), else unused */
 } LbGemmParams;
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
@@ -157,7 +157,7 @@ void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = dir
 /* Experiment knob: input bytes per statistics+apply pair (sample groups sized for the Infinity Cache); default 0 = one
  * pair over the whole batch, which measured faster at every group size (profiles/r02_groupnorm_l3.txt). */
 void lb_groupnorm_set_l3_chunk(long bytes);
-/* GroupNorm whose statistics were left by the producing conv (LB_GEMM_CH_STATS): ch_stats = [B * stat_rows_per_sample][C]
+/* GroupNorm whose statistics were left by the producing conv (LB_GEMM_CH_STATS): ch_stats = [C][B * stat_rows_per_sample]
  * float2; a small fold launch (float64, fixed order) + the same apply pass as lb_groupnorm_nhwc - x is read ONCE. */
 int lb_groupnorm_from_stats(const void* x, void* y, const float* gamma, const float* beta, const float* ch_stats,
                             void* workspace, int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,

@@ -302,9 +302,10 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         asm volatile("" : "+v"(col0));
         if (!(study & 1)) {
             if (p.flags & LB_GEMM_CH_STATS) {   // (wave-uniform) GroupNorm statistics of the stored tile: row block (item / n_blocks) * 4 + wave_m
-                float2* chst = reinterpret_cast<float2*>(p.ch_stats) + ((long)(item / n_blocks) * 4 + wave_m) * p.N;
+                const long stat_rows = (long)(n_items / n_blocks) * 4;          // row blocks of the whole launch
+                float2* chst = reinterpret_cast<float2*>(p.ch_stats) + ((long)(item / n_blocks) * 4 + wave_m);
                 lb_gemm_tile_epilogue_rows_ln<TM, TN, false, false, true>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0,
-                                                                          (const LbLnRows<TM>*)nullptr, chst);
+                                                                          (const LbLnRows<TM>*)nullptr, chst, stat_rows);
             } else {
                 lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
             }

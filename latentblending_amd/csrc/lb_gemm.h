@@ -116,12 +116,13 @@ __device__ __forceinline__ void lb_row16_reduce32(const float (&v)[32], float (&
 }
 
 // CHST (LB_GEMM_CH_STATS, halo conv kernels): per output column, (sum, sum of squares) over the wave's 16 TM rows of the
-// values this epilogue STORES (after the fp16 rounding when the output is fp16) go to chst[n] (float2): each lane sums its
+// values this epilogue STORES (after the fp16 rounding when the output is fp16) go to chst[n * chst_ld] (float2: the statistics
+// buffer is CHANNEL-major, [N][row blocks], so that the fold kernel reads a group's channels as contiguous runs): each lane sums its
 // TM rows, the 16 lanes that share a column quad (l16 = 0..15) fold them with a DPP butterfly (fixed order), two values per lane.
 template <int TM, int TN, bool GEGLU, bool LNA, bool CHST = false, typename RowFn>
 __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams& p, const f32x4 (&acc)[TM][TN],
                                                            RowFn row_of, int col0, int gcol0, const LbLnRows<TM>* ln,
-                                                           float2* chst = nullptr) {
+                                                           float2* chst = nullptr, long chst_ld = 1) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (GEGLU) {
         constexpr int TP = TN / 2 > 0 ? TN / 2 : 1;
@@ -320,9 +321,9 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
         const int which = l & 1, j = ((l >> 1) & 1) * 2 + ((l >> 2) & 1), r0 = (l >> 3) * 2;     // the two values this lane holds
         const int n = col0 + j * 16 + r0;
         if (n < p.N) {          // (N % 4 == 0: columns n and n + 1 are valid together)
-            float* f = reinterpret_cast<float*>(chst);
-            f[2 * n + which] = red[0];
-            f[2 * n + 2 + which] = red[1];
+            float* f = reinterpret_cast<float*>(chst);        // chst = &stats[0][row block]; channel n lives chst_ld float2 further on
+            f[2 * (long)n * chst_ld + which] = red[0];
+            f[2 * (long)(n + 1) * chst_ld + which] = red[1];
         }
     }
 }

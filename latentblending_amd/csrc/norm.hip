@@ -281,21 +281,22 @@ extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, con
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm from statistics the PRODUCING conv left behind (LB_GEMM_CH_STATS, conv3_halo.hip): ch_stats holds, per
-// (64-pixel row block, channel), (sum, sum of squares) of the stored values.  gn_fold_stats folds them per (sample, group)
-// in float64 - thread t takes rows t, t + 256, ... (all channels of the group), then a fixed-order block reduction - into
+// (channel, 64-pixel row block) - channel-major, so a group's channels are contiguous runs - (sum, sum of squares) of the
+// stored values.  gn_fold_stats folds them per (sample, group) in float64 - thread t takes rows t, t + 256, ... of every
+// channel of the group, then a fixed-order block reduction - into
 // the SAME partial[b][0][group] slot layout gn_apply_kernel consumes (nchunk = 1): x is read once, by the apply pass.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gn_fold_stats_kernel(const float2* __restrict__ ch_stats, double* __restrict__ partial,
-                                                            int C, int groups, int rows_per_sample) {
+                                                            int C, int groups, int rows_per_sample, long total_rows) {
     __shared__ double red_s[256], red_q[256];
     const int grp = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / groups;
-    const float2* base = ch_stats + ((long)b * rows_per_sample) * C + grp * cpg;
+    // channel-major buffer [C][total_rows]: channel c of sample b is the contiguous run [c][b * rows_per_sample ..]
     double s = 0, q = 0;
-    for (int r = tid; r < rows_per_sample; r += 256) {
-        const float2* row = base + (long)r * C;
-        for (int c = 0; c < cpg; ++c) {
-            const float2 v = row[c];
+    for (int c = 0; c < cpg; ++c) {
+        const float2* run = ch_stats + (long)(grp * cpg + c) * total_rows + (long)b * rows_per_sample;
+        for (int r = tid; r < rows_per_sample; r += 256) {
+            const float2 v = run[r];
             s += (double)v.x;
             q += (double)v.y;
         }
@@ -319,7 +320,7 @@ static int groupnorm_from_stats_impl(const void* x, void* y, const float* gamma,
                                      int x_is_f32, int rows_per_sample, hipStream_t stream) {
     double* partial = (double*)workspace;
     hipLaunchKernelGGL(gn_fold_stats_kernel, dim3(groups, B), dim3(256), 0, stream, (const float2*)ch_stats, partial, C, groups,
-                       rows_per_sample);
+                       rows_per_sample, (long)B * rows_per_sample);
     int rc = lb_check_launch("lb_groupnorm_from_stats(fold)");
     if (rc) return rc;
     const int vecs = C / 8;

@@ -255,7 +255,7 @@ def conv_halo_plan(B: int, H: int, W: int, cin: int, cout: int, ks: int = 3):
 def groupnorm_from_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
                          ch_stats: torch.Tensor, rows_per_sample: int) -> torch.Tensor:
     """GroupNorm of x [B, H, W, C] whose (sum, sum of squares) per (64-pixel row block, channel) the producing conv left in
-    ``ch_stats`` ([B * rows_per_sample, C, 2] fp32, LB_GEMM_CH_STATS)."""
+    ``ch_stats`` ([C, B * rows_per_sample, 2] fp32, channel-major, LB_GEMM_CH_STATS)."""
     B, C_ = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * C_)
     y = torch.empty(x.shape, dtype=F16, device=x.device)

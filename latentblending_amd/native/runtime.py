@@ -222,7 +222,7 @@ class Emitter:
         return t.value, sk.value
 
     def halo_stat_rows(self, B: int, H: int, W: int, cin: int, cout: int, ks: int = 3) -> int:
-        """Rows per sample of the LB_GEMM_CH_STATS buffer ([B * rows][cout] float2) if a 3x3 conv (ks = 3) or a one-launch
+        """Rows per sample of the LB_GEMM_CH_STATS buffer ([cout][B * rows] float2, channel-major) if a 3x3 conv (ks = 3) or a one-launch
         sub-pixel upsampler conv (ks = 2) of this geometry runs on the halo-tile kernel - whose epilogue can leave the
         GroupNorm statistics of what it stores - else 0 (the consumer then runs the two-pass GroupNorm)."""
         p = LbGemmParams()

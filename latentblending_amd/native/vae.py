@@ -156,7 +156,7 @@ class VAEProgram:
         rows = self.em.halo_stat_rows(B, H, W, cin_p, cout_p, ks) if self.fuse_gn_stats else 0
         if not rows:
             return None
-        buf = self.arena.alloc((B * rows, cout_p, 2), F32)
+        buf = self.arena.alloc((cout_p, B * rows, 2), F32)        # channel-major
         out._lb_chstats = (buf, rows)
         return buf
 

@@ -726,7 +726,7 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
     kind, tw, items, grid = o.conv_halo_plan(B, H, H, Cin, Cout)
     assert kind == 3
     rows = items // ((Cout + 127) // 128) // B * 4
-    st = torch.full((B * rows, Cout, 2), float("nan"), dtype=torch.float32, device=DEV)
+    st = torch.full((Cout, B * rows, 2), float("nan"), dtype=torch.float32, device=DEV)          # channel-major
     flags = l.GEMM_OUT_F32 if f32 else 0
     l.api.lb_gemm_set_halo(2)
     try:
@@ -739,7 +739,7 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
     assert torch.equal(y, y_plain), "the statistics epilogue must not change what the conv stores"
     assert torch.isfinite(st).all(), "every (row block, channel) slot must be written"
     yf = y.float().reshape(B, H * H, Cout)
-    tot = st.reshape(B, rows, Cout, 2).double().sum(dim=1).cpu()
+    tot = st.reshape(Cout, B, rows, 2).double().sum(dim=2).permute(1, 0, 2).cpu()
     want_s, want_q = yf.double().sum(dim=1).cpu(), (yf.double() ** 2).sum(dim=1).cpu()
     assert torch.allclose(tot[..., 0], want_s, rtol=1e-4, atol=1e-2) and torch.allclose(tot[..., 1], want_q, rtol=1e-4, atol=1e-2)
     gamma, beta = (1 + 0.1 * rnd(Cout, seed=215, dtype=torch.float32)).to(DEV), (0.1 * rnd(Cout, seed=216, dtype=torch.float32)).to(DEV)
