@@ -124,7 +124,7 @@ def gemm_family_profile(pipe, launches):
                     tot["halo_flops"] += glog[gi]["flops"] * cnt
                     tot["halo_launches"] += cnt
                 gi += 1
-            elif n == "lb_attn_fwd_d64":
+            elif n in ("lb_attn_fwd_d64", "lb_attn_fwd_d512"):
                 a = alog[ai]
                 tot["attn_flops"] += a["flops"] * cnt
                 tot["attn_ms"] += t * cnt

@@ -172,17 +172,21 @@ int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* be
 /* ---- attention (AttnProcessor2_0 / scaled_dot_product_attention inside the UNet call at
  *      diffusers_holder.py:336; VAE mid-block attention at :135) ------------------------ */
 typedef struct LbAttnParams {
-    const lb_half* Q;    /* element (b, q, h, d) at Q[(b*Sq + q)*ldq + h*64 + d] */
-    const lb_half* K;    /* element (b, k, h, d) at K[(b*Skv + k)*ldk + h*64 + d] */
-    const lb_half* V;    /* element (b, k, h, d) at V[(b*Skv + k)*ldv + h*64 + d]  (token-major, like K) */
+    const lb_half* Q;    /* element (b, q, h, d) at Q[(b*Sq + q)*ldq + h*D + d], D = the head dim of the entry point (64 / 512) */
+    const lb_half* K;    /* element (b, k, h, d) at K[(b*Skv + k)*ldk + h*D + d] */
+    const lb_half* V;    /* element (b, k, h, d) at V[(b*Skv + k)*ldv + h*D + d]  (token-major, like K) */
     lb_half* O;          /* like Q with ldo */
     int B, H, Sq, Skv, Skv_valid;   /* keys >= Skv_valid are masked (context padding 77 -> 80) */
     int ldq, ldk, ldv, ldo;         /* Q, K, V may be column slices of one fused [tokens][3C] projection */
-    float scale;         /* 1/sqrt(64) */
+    float scale;         /* 1/sqrt(D) */
     int causal;          /* 1: key k is visible to query q only when k <= q (CLIP text towers); needs Sq == Skv */
     const void* zero_page;          /* >= 16 zero bytes, 16-B aligned: source of the direct-to-LDS loads of rows >= Skv */
 } LbAttnParams;
 int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
+/* head dim 512, no causal form: the VAE decoder's mid-block attention (AutoencoderKL.decode, diffusers_holder.py:135) as ONE launch -
+ * no S x S score matrix exists (the three-launch form scores GEMM -> lb_softmax_rows_f16 -> PV GEMM wrote 32 MB per sample at 512^2,
+ * 512 MB at 1024^2) */
+int lb_attn_fwd_d512(const LbAttnParams* params, void* stream);
 void lb_attn_set_tuning(int force);   /* testing: 0 = by shape; bits 0-1 = query groups per wave (1 / 2), bit 4 = always stream 64-key tiles */
 int lb_softmax_rows_f16(void* x, int M, int N, int ld, float scale, void* stream);
 

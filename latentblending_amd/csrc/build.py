@@ -16,7 +16,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 
 # per-source extra flags (see the header comment of the file for the reason)
-EXTRA_FLAGS = {"attn.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+_ATTN_FLAGS = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+EXTRA_FLAGS = {"attn.hip": _ATTN_FLAGS, "attn512.hip": _ATTN_FLAGS}
 
 
 def sources():

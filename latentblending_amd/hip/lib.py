@@ -83,6 +83,7 @@ SIGNATURES = {
     "lb_groupnorm_from_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp]),
     "lb_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lb_attn_fwd_d64": (_i, [C.POINTER(LbAttnParams), _vp]),
+    "lb_attn_fwd_d512": (_i, [C.POINTER(LbAttnParams), _vp]),
     "lb_attn_set_tuning": (None, [_i]),
     "lb_softmax_rows_f16": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "lb_sinusoid_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),

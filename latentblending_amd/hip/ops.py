@@ -302,6 +302,22 @@ def attention_d64(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: 
     return out
 
 
+def attention_d512(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int, Sq: int, Skv: int,
+                   skv_valid: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Head dim 512 (the VAE mid-block attention): q [B*Sq, >=H*512], k, v [B*Skv, >=H*512]; one launch, no S x S buffer."""
+    p = LbAttnParams()
+    if out is None:
+        out = torch.empty(B * Sq, H * 512, dtype=F16, device=q.device)
+    p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, skv_valid or Skv
+    p.ldq, p.ldk, p.ldv, p.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    p.scale = 512.0 ** -0.5
+    p.causal = 0
+    p.zero_page = zero_page(q.device).data_ptr()
+    api.lb_attn_fwd_d512(C.byref(p), stream_ptr())
+    return out
+
+
 def softmax_rows_(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     M, N = x.shape
     api.lb_softmax_rows_f16(x.data_ptr(), M, N, x.stride(0), scale, stream_ptr())

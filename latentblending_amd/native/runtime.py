@@ -275,16 +275,18 @@ class Emitter:
         return out
 
     def attention(self, q_ptr: int, k_ptr: int, v_ptr: int, out: torch.Tensor, *, B, H, Sq, Skv, valid,
-                  ldq, ldk, ldv, ldo, causal: bool = False):
+                  ldq, ldk, ldv, ldo, causal: bool = False, head_dim: int = 64):
+        """``head_dim`` 64: lb_attn_fwd_d64 (UNet, CLIP towers); 512: lb_attn_fwd_d512 (VAE mid block, no causal form)."""
+        assert head_dim in (64, 512) and not (causal and head_dim == 512)
         p = LbAttnParams()
         p.Q, p.K, p.V, p.O = q_ptr, k_ptr, v_ptr, out.data_ptr()
         p.B, p.H, p.Sq, p.Skv, p.Skv_valid = B, H, Sq, Skv, valid
         p.ldq, p.ldk, p.ldv, p.ldo = ldq, ldk, ldv, ldo
-        p.scale = 0.125
+        p.scale = float(head_dim) ** -0.5
         p.causal = int(causal)
         p.zero_page = self.zero_page.data_ptr()
-        api.lb_attn_fwd_d64(C.byref(p), _stream())
-        self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * 64, "Sq": Sq, "Skv": Skv})
+        (api.lb_attn_fwd_d512 if head_dim == 512 else api.lb_attn_fwd_d64)(C.byref(p), _stream())
+        self.attn_log.append({"flops": 4.0 * B * H * Sq * valid * head_dim, "Sq": Sq, "Skv": Skv, "head_dim": head_dim})
         return out
 
     def copy_cols(self, src, dst, *, rows, cols, ld_src, ld_dst, dst_off):

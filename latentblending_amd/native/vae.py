@@ -44,6 +44,7 @@ class VAEConfig:
     force_upcast: bool = True
     stream_fp16_scaled: bool = True      # residual stream as fp16 * 2^-4 (False: fp32 stream)
     fuse_gn_stats: bool = True           # GroupNorm statistics from the producing conv's epilogue (LB_GEMM_CH_STATS): one pass over x
+    fused_mid_attention: bool = True     # 512-channel mid-block attention as one lb_attn_fwd_d512 launch (no S x S score buffer)
 
     @property
     def scale_factor(self) -> int:
@@ -112,6 +113,10 @@ class NativeVAEDecoder:
         self.w[a + ".to_v.weight"] = self._dev(wv, F16)
         self.w[a + ".to_out.0.weight"] = self._dev(wo, F16)
         self.w[a + ".to_out.0.bias"] = self._dev(bo + wo.half().float() @ bv, F32)   # V bias folded
+        if top == 512:                      # fused form: ONE q | k | v projection feeding lb_attn_fwd_d512 (V bias folded as above)
+            self.w[a + ".qkv.weight"] = torch.cat([self.w[a + ".to_q.weight"], self.w[a + ".to_k.weight"], self.w[a + ".to_v.weight"]], 0).contiguous()
+            self.w[a + ".qkv.bias"] = torch.cat([self.w[a + ".to_q.bias"], self.w[a + ".to_k.bias"],
+                                                 torch.zeros_like(self.w[a + ".to_q.bias"])], 0).contiguous()
         self._resnet(pv, "decoder.mid_block.resnets.1", top, top)
         prev = top
         for ui, c in enumerate(rev):
@@ -135,6 +140,7 @@ class VAEProgram:
         self.net, self.B, self.L = net, B, L
         self.scaled = bool(cfg.stream_fp16_scaled)
         self.fuse_gn_stats = bool(getattr(cfg, "fuse_gn_stats", True))
+        self.fused_mid_attention = bool(getattr(cfg, "fused_mid_attention", True))
         dev = net.device
         self.arena = Arena(dev)
         self.em = Emitter(self.arena)
@@ -224,6 +230,15 @@ class VAEProgram:
         S = H * W
         n = ar.alloc((B * S, c))
         self._gn(h, n, a + ".group_norm", B, S, c, False)
+        if self.fused_mid_attention and (a + ".qkv.weight") in w:
+            qkv = ar.alloc((B * S, 3 * c))
+            em.gemm(n, w[a + ".qkv.weight"], qkv, M=B * S, bias=w[a + ".qkv.bias"])
+            ar.release(n)
+            o = ar.alloc((B * S, c))
+            em.attention(qkv.data_ptr(), qkv.data_ptr() + 2 * c, qkv.data_ptr() + 4 * c, o, B=B, H=1, Sq=S, Skv=S, valid=S,
+                         ldq=3 * c, ldk=3 * c, ldv=3 * c, ldo=c, head_dim=512)
+            ar.release(qkv)
+            return self._attn_out(o, h, B, S)
         q, k = ar.alloc((B * S, c)), ar.alloc((B * S, c))
         em.gemm(n, w[a + ".to_q.weight"], q, M=B * S, bias=w[a + ".to_q.bias"])
         em.gemm(n, w[a + ".to_k.weight"], k, M=B * S, bias=w[a + ".to_k.bias"])
@@ -238,6 +253,11 @@ class VAEProgram:
             api.lb_softmax_rows_f16(scores.data_ptr(), S, S, S, 1.0, _stream())
             em.gemm(scores, vt[:, b * S:(b + 1) * S], ob, M=S, lda=S)    # W = V^T slice [c, S], ldw = B*S
         ar.release(scores); ar.release(q); ar.release(k); ar.release(vt)
+        return self._attn_out(o, h, B, S)
+
+    def _attn_out(self, o, h, B, S):
+        em, w, ar, sc = self.em, self.net.w, self.arena, self.scaled
+        a = "decoder.mid_block.attentions.0"
         em.gemm(o, w[a + ".to_out.0.weight"], h, M=B * S, bias=w[a + (".to_out.0.bias_s" if sc else ".to_out.0.bias")],
                 residual=h, flags=0 if sc else (lib.GEMM_OUT_F32 | lib.GEMM_RES_F32), alpha=STREAM_SCALE if sc else 1.0)
         ar.release(o)

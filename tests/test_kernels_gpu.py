@@ -512,6 +512,37 @@ def test_attention_spiked_scores(results_log):
     check_close(results_log, "attn_spiked", got.reshape(B, S, C), ref, floor=2e-3)
 
 
+@pytest.mark.parametrize("case", [(2, 1, 1024, 1024, 1024), (1, 1, 4096, 4096, 4096), (1, 2, 200, 200, 200), (2, 1, 100, 77, 70),
+                                  (1, 1, 64, 32, 32), (3, 1, 130, 33, 33)])
+def test_attention_d512(case, results_log):
+    """lb_attn_fwd_d512 (the VAE mid-block attention as one launch) vs fp32 softmax attention: full tiles, ragged query and key
+    counts, masked key tail, several heads of 512."""
+    o = ops()
+    B, H, Sq, Skv, valid = case
+    C = H * 512
+    q, k, v = rnd(B, Sq, C, seed=151), rnd(B, Skv, C, seed=152), rnd(B, Skv, C, seed=153)
+    ref = R.attention(q.float(), k.float()[:, :valid], v.float()[:, :valid], H)
+    got = o.attention_d512(q.reshape(B * Sq, C).to(DEV), k.reshape(B * Skv, C).to(DEV), v.reshape(B * Skv, C).to(DEV),
+                           B, H, Sq, Skv, valid)
+    check_close(results_log, f"attn512_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
+
+
+def test_attention_d512_fused_qkv_and_spikes(results_log):
+    """Operands as column slices of one [tokens][3 * 512] projection (the VAE program's layout), with keys far above the rest
+    placed in late tiles (deferred-rescale path) and a query row scaled up (large scores: the fp32 score path)."""
+    o = ops()
+    B, S, C = 2, 512, 512
+    qkv = rnd(B, S, 3 * C, seed=154)
+    qkv[0, 300, C:2 * C] = qkv[0, 5, :C] * 3.0
+    qkv[1, 40, C:2 * C] = qkv[1, 400, :C] * 2.0
+    qkv[1, 7, :C] *= 4.0
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    ref = R.attention(q.float(), k.float(), v.float(), 1)
+    d = qkv.reshape(B * S, 3 * C).to(DEV)
+    got = o.attention_d512(d[:, :C], d[:, C:2 * C], d[:, 2 * C:], B, 1, S, S)
+    check_close(results_log, "attn512_fused_qkv_spiked", got.reshape(B, S, C), ref, floor=2e-3)
+
+
 def test_softmax_rows(results_log):
     o = ops()
     x = rnd(300, 4096, seed=57, scale=4.0)

@@ -22,7 +22,7 @@ def table(prog, glog, alog, title, fh):
             halo = n != "lb_gemm_f16"
             rows.append((t, f"gemm{'(halo conv)' if halo else '(conv)' if g['conv'] else ''} M={g['M']} N={g['N']} K={g['K']}", g["flops"]))
             by_kind["conv_halo" if halo else "gemm_conv" if g["conv"] else "gemm"] += t
-        elif n == "lb_attn_fwd_d64":
+        elif n in ("lb_attn_fwd_d64", "lb_attn_fwd_d512"):
             a = alog[ai]; ai += 1
             rows.append((t, "attn", a["flops"]))
             by_kind["attn"] += t
