@@ -385,10 +385,11 @@ def skewed_metric(be, skew):
 
 
 def secondary_lines(pipe, args, branches):
-    """Two more lines for the driver's record (same process, same resident weights), each best-effort:
+    """More lines for the driver's record (same process, same resident weights), each best-effort:
     * the metric's workload under a deliberately SKEWED perceptual metric (distance x exp(3 x position)): the greedy order
       leaves the balanced tree, the speculative frontier needs several rounds and drops speculated branches - the other end
       of the range real LPIPS on real images will sit in (the headline's synthetic weights give a balanced tree: 1 round);
+    * the opt-in dead-step elision; a chain of transitions with and without pipelined key frames (SURVEY.md §8f rank 3);
     * BASELINE configs[2]: SDXL base 1024^2, 30 steps, guidance 4.0 (CFG), depth_strength 0.5, nmb_max_branches 15."""
     import latentblending_amd.native as N
     from latentblending_amd import BlendingEngine
@@ -435,6 +436,35 @@ def secondary_lines(pipe, args, branches):
                     "ms_per_step": dt * 1e3, "unet_samples_per_transition": (pipe.stats["unet_samples"] - before) / 4})
     except Exception as exc:
         out.append({"name": "cfg2 with elide_dead_steps", "error": repr(exc)})
+    try:    # a chain of transitions (example_multi_trans.py:39-58) at the metric's settings, the sequential
+        # loop vs all key frames denoised ahead of the transitions (replay.run_multi_transition(pipeline_keyframes=True))
+        from latentblending_amd import replay
+        prompts = ["photo of underwater landscape, fish, und the sea, incredible detail, high resolution",
+                   "rendering of an alien planet, strange plants, strange creatures, surreal",
+                   "photo of a forest in the fog, sun rays", "aerial photo of a city at night", "macro photo of a dragonfly"]
+        seeds = [420, 421, 422, 423, 424]
+        chain = {}
+        for piped in (False, True, False, True):
+            be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+            be.host_frames = True
+            be.set_branching(nmb_max_branches=branches)
+            if not chain:
+                replay.run_multi_transition(be, prompts[:3], seeds[:3], None, pipeline_keyframes=True)     # warm-up: programs of every batch size
+                replay.run_multi_transition(be, prompts[:3], seeds[:3], None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            segs = replay.run_multi_transition(be, prompts, seeds, None, pipeline_keyframes=piped)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            chain.setdefault(piped, []).append((sum(len(s_) for s_ in segs), dt))
+        best = {k: min(v, key=lambda fd: fd[1]) for k, v in chain.items()}
+        out.append({"name": "chain of 4 transitions (5 prompts) at the cfg2 settings: sequential loop (recycle_img1) vs key frames pipelined "
+                            "(replay.run_multi_transition(pipeline_keyframes=True))", "unit": "frames/s",
+                    "sequential": best[False][0] / best[False][1], "value": best[True][0] / best[True][1],
+                    "ms_per_transition_sequential": best[False][1] * 250.0, "ms_per_transition_pipelined": best[True][1] * 250.0,
+                    "frames": best[True][0]})
+    except Exception as exc:
+        out.append({"name": "chain of transitions, pipelined key frames", "error": repr(exc)})
     try:
         base_pipe = N.NativeSDXLPipe(turbo=False, unet_native=pipe.unet_native, vae_native=pipe.vae_native, device=str(pipe.device),
                                      allow_synthetic=True)

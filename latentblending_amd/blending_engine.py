@@ -24,7 +24,7 @@ from __future__ import annotations
 import os
 import platform
 import time
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -101,6 +101,7 @@ class BlendingEngine:
         self.image2_lowres = None
         self.negative_prompt = None
         self.stats = {}
+        self._preset_anchor_frames = None      # (frame of anchor 1, frame of anchor 2) for the next transition: see preset_anchors
 
         self.set_guidance_scale()
         self.multi_transition_img_first = None
@@ -310,7 +311,9 @@ class BlendingEngine:
     def _grow_tree(self, first, last, prefilled, use_frontier):
 
         if prefilled is None:
-            frames = self._decode_many([first[-1], last[-1]])
+            frames, self._preset_anchor_frames = self._preset_anchor_frames, None
+            if frames is None:
+                frames = self._decode_many([first[-1], last[-1]])
             self._tree.reset(first, last, frames[0], frames[1])
 
         for level in tqdm(range(len(self.list_idx_injection)), disable=not self.verbose):
@@ -343,6 +346,10 @@ class BlendingEngine:
             float(self.branch1_crossfeed_power), float(self.parental_crossfeed_power), float(self.parental_crossfeed_range),
             float(self.parental_crossfeed_decay), float(self.seed1), float(self.seed2), float(bool(keep1)), float(bool(keep2))]
         self.farm.check_consistent(plan, "branching plan / settings")
+        return self._farm_shared_noise()
+
+    def _farm_shared_noise(self):
+        """Ancestral noise as ONE stream on every rank (see ``_farm_begin``); returns the restore callable or None."""
         sched = getattr(self.dh.pipe, "scheduler", None)
         if _is_native(self.dh.pipe) and getattr(sched, "ancestral", False) and sched.noise_source is None:
             from .native.scheduler import SeededDeviceNoise
@@ -404,6 +411,65 @@ class BlendingEngine:
         # (dt_unet_step keeps its benchmark_speed() value: a batched, asynchronous run is not a per-step timing)
         self.tree_latents[0], self.tree_latents[-1] = first, last
         return first, last
+
+    def precompute_keyframes(self, embeddings: Sequence, seeds: Sequence[int]):
+        """Cross-transition pipelining of a multi-transition chain (the loop of the reference's
+        example_multi_trans.py:39-58 diffuses key frame k+1 only when transition k starts, one latency-bound batch-1
+        trajectory per transition): ALL key frames are denoised ahead of the transitions - one lock-step batch on a
+        native pipe, key frame k on rank ``k % world`` under a farm (then broadcast, C1 of §8e) - and decoded in one
+        VAE batch.  ``embeddings[k]`` is the embedding tuple of prompt k, ``seeds[k]`` its seed.  Returns
+        ``(trajectories, frames)``; ``replay.run_multi_transition(pipeline_keyframes=True)`` hands them to
+        ``run_transition(recycle_img1=True, recycle_img2=True)`` through ``tree_latents`` / ``preset_anchor_frames``.
+
+        Differences from the sequential chain, by construction: every key frame is denoised with the guidance scale
+        current at this call (the sequential loop leaves the mid-dampened scale of the previous transition's last
+        branch for the next key frame, blending_engine.py:266-270 + :531 of the reference), and an ancestral noise
+        stream is consumed key frame by key frame before any mid branch draws from it.  Not available with
+        ``branch1_crossfeed_power > 0`` (key frame k+1 then depends on key frame k)."""
+        assert self.branch1_crossfeed_power == 0.0, "precompute_keyframes: key frames are only independent without branch1 crossfeed"
+        assert len(embeddings) == len(seeds) and len(embeddings) >= 1
+        steps, n = self.num_inference_steps, len(embeddings)
+        self.dh.set_num_inference_steps(steps)
+        pipe = self.dh.pipe
+        farm = self.farm if self._farm_on() else None
+        ancestral = bool(getattr(getattr(pipe, "scheduler", None), "ancestral", False))
+        restore_noise = self._farm_shared_noise() if farm else None
+        try:
+            mine = [k for k in range(n) if farm is None or farm.owner_of(k) == farm.rank]
+            trajs = [None] * n
+            if _is_native(pipe):
+                if mine:
+                    zeros = [0.0] * steps
+                    got = pipe.native_run_diffusion_batch(
+                        [embeddings[k] for k in mine], [self.get_noise(int(seeds[k])) for k in mine], 0, [None] * len(mine),
+                        [zeros] * len(mine), num_inference_steps=steps, guidance_scales=[self.guidance_scale] * len(mine),
+                        noise_slots=(n, mine) if farm else None)
+                    for k, t in zip(mine, got):
+                        trajs[k] = t
+            else:
+                for k in range(n):                       # (generic pipes: one trajectory at a time, in chain order)
+                    if k in mine:
+                        trajs[k] = self.run_diffusion([embeddings[k]], latents_start=self.get_noise(int(seeds[k])), idx_start=0)
+                    elif ancestral:
+                        self._skip_noise_draws(steps)
+            if farm:
+                shape = (1,) + self._latent_chw()
+                for k in range(n):
+                    owner = farm.owner_of(k)
+                    trajs[k] = self._on_pipe_device(farm.share_trajectory(trajs[k] if owner == farm.rank else None, owner, steps, shape))
+            frames = self._decode_many([t[-1] for t in trajs])      # every rank decodes the same batch: identical frames
+        finally:
+            if restore_noise is not None:
+                restore_noise()
+        self._sync()
+        self.stats["keyframes_precomputed"] = self.stats.get("keyframes_precomputed", 0) + n
+        return trajs, frames
+
+    def preset_anchors(self, first, last, frame_first=None, frame_last=None):
+        """Install two finished anchor trajectories (and, optionally, their decoded frames) for the next
+        ``run_transition(recycle_img1=True, recycle_img2=True)``."""
+        self.tree_latents[0], self.tree_latents[-1] = first, last
+        self._preset_anchor_frames = (frame_first, frame_last) if frame_first is not None and frame_last is not None else None
 
     def _parental_mix(self, b_parent1, b_parent2, fract_parental):
         """Slerp the two parents' trajectories step by step (``None`` where either has no latent)."""

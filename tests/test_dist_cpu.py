@@ -134,6 +134,51 @@ def test_branch_farm_recycled_anchor_matches_single_process(tmp_path):
     assert abs(r0[1]["last_norm"] - solo[1]["last_norm"]) <= 1e-3 * solo[1]["last_norm"]
 
 
+def _pipelined_chain_worker(rank, world, port, out_dir):
+    """Three prompts, replay.run_multi_transition(pipeline_keyframes=True): key frame k is denoised on rank k % world and
+    broadcast; ancestral noise from a tape (non-owners skip the draws); world 1 = the farm-less engine."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine, replay
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    set_backend(R.TorchCpuBackend())
+    p = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+    np.random.seed(0)
+    farm = BranchFarm() if world > 1 else None
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=3, farm=farm)
+    be.set_dimensions((128, 128))
+    be.set_branching(nmb_max_branches=4)
+    p.noise.reset()
+    p.unet.calls = 0
+    segs = replay.run_multi_transition(be, ["photo of a reef", "rendering of an alien planet", "a forest in the fog"],
+                                       [420, 421, 999], None, pipeline_keyframes=True)
+    out = {"frames": [[int(np.asarray(i).astype(np.int64).sum()) for i in seg] for seg in segs],
+           "fracts": [float(f) for f in be.tree_fracts], "unet_calls": p.unet.calls,
+           "last_norm": float(be.tree_latents[-1][-1].float().norm())}
+    json.dump(out, open(os.path.join(out_dir, f"pipe_rank{rank}_of{world}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_pipelined_keyframes_match_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_pipelined_chain_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_pipelined_chain_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    solo = json.load(open(tmp_path / "pipe_rank0_of1.json"))
+    r0, r1 = [json.load(open(tmp_path / f"pipe_rank{r}_of2.json")) for r in (0, 1)]
+    assert r0["frames"] == r1["frames"] and r0["fracts"] == r1["fracts"], "ranks diverged"
+    assert r0["frames"] == solo["frames"] and r0["fracts"] == solo["fracts"]
+    assert len(solo["frames"]) == 2 and solo["frames"][0][-1] == solo["frames"][1][0]      # the shared key frame
+    assert abs(r0["last_norm"] - solo["last_norm"]) <= 1e-3 * solo["last_norm"]
+    # the three key-frame trajectories were split 2 / 1 between the ranks
+    assert r0["unet_calls"] + r1["unet_calls"] < 2 * solo["unet_calls"]
+
+
 def _mismatch_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

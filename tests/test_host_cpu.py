@@ -492,6 +492,53 @@ def test_multi_transition_driver_and_movie_json(tmp_path, cpu_backend):
         replay.load_movie_json(bad)
 
 
+def test_pipelined_keyframes_chain_equals_the_sequential_chain(cpu_backend):
+    """replay.run_multi_transition(pipeline_keyframes=True): all key frames denoised ahead of the transitions
+    (BlendingEngine.precompute_keyframes), every transition with both anchors recycled.  On a deterministic sampler
+    (SDXL-base config: Euler, CFG) the frames must be bit-identical to the sequential loop of example_multi_trans.py:39-58
+    written out by hand - once that loop's one quirk is removed: it denoises key frame k+1 with the mid-dampened guidance
+    scale the previous transition's last branch left behind; the pipelined form uses the scale current at the start."""
+    from latentblending_amd import BlendingEngine, replay
+
+    def engine():
+        p = tiny_pipe(turbo=False)
+        np.random.seed(0)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+        be.set_dimensions((128, 128)); be.set_num_inference_steps(4); be.set_guidance_scale(3.0)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=3)
+        return p, be
+
+    prompts = ["a reef", "an alien planet", "a city at night"]
+    negs = ["blurry", "pale", "lofi"]
+    seeds = [11, 12, 13]
+    p1, be1 = engine()
+    hand = []
+    for i in range(2):
+        if i == 0:
+            be1.set_prompt1(prompts[0]); be1.set_negative_prompt(negs[0]); be1.set_prompt2(prompts[1])
+        else:
+            be1.guidance_scale = be1.dh.guidance_scale = 3.0         # (the quirk, removed)
+            be1.swap_forward(); be1.set_negative_prompt(negs[i + 1]); be1.set_prompt2(prompts[i + 1])
+        hand.append([np.asarray(f) for f in be1.run_transition(recycle_img1=i > 0, fixed_seeds=seeds[i:i + 2])])
+    p2, be2 = engine()
+    seen = []
+    segs = replay.run_multi_transition(be2, prompts, seeds, None, list_negative_prompts=negs, pipeline_keyframes=True,
+                                       on_segment=lambda i, fr: seen.append(i))
+    assert seen == [0, 1] and be2.stats["keyframes_precomputed"] == 3
+    assert p2.unet.calls == p1.unet.calls                  # the same trajectories, only earlier
+    assert p2.vae.calls < p1.vae.calls                     # every key frame decoded once (the loop decodes a recycled anchor again)
+    for a, b in zip(hand, segs):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, np.asarray(y))
+    assert np.array_equal(np.asarray(segs[0][-1]), np.asarray(segs[1][0]))
+    assert be2.negative_prompt == be1.negative_prompt and be2.prompt2 == be1.prompt2
+    # key frames depend on each other under branch1 crossfeed: refused
+    be2.set_branch1_crossfeed(0.3, 0.5, 0.5)
+    with pytest.raises(AssertionError):
+        replay.run_multi_transition(be2, prompts, seeds, None, pipeline_keyframes=True)
+
+
 def test_gemm_tile_policy_is_pinned():
     """lb_gemm_plan (pure host arithmetic of the launcher): the tile / split-K choices the MI355X sweeps led to
     (profiles/r01_gemm_*.txt, tools/ab_policy.py) for the shapes the SDXL programs launch.  Tiles: 1 = 128x128,

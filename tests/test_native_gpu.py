@@ -226,6 +226,37 @@ def test_chained_transitions_match_oracle(results_log):
     assert d1.mean() <= 2 and d2.mean() <= 2 and err <= 3e-2
 
 
+def test_pipelined_keyframe_chain_matches_oracle(results_log):
+    """replay.run_multi_transition(pipeline_keyframes=True): the native engine denoises all key frames as ONE lock-step batch
+    (native_run_diffusion_batch, noise drawn sample-major) and decodes them in one VAE batch; the same driver over the CPU
+    oracle pipe walks them one by one.  Same trees in every transition, shared key frames, frames within tolerance."""
+    from latentblending_amd import BlendingEngine, replay
+    from latentblending_amd.backend import set_backend
+    o, p, tape = make_pair(turbo=True)
+    prompts, seeds = ["photo of a reef", "rendering of an alien planet", "a forest in the fog"], [420, 421, 999]
+    res = {}
+    for name, pipe_, backend in (("oracle", o, R.TorchCpuBackend()), ("native", p, None)):
+        set_backend(backend)
+        np.random.seed(0)
+        be = BlendingEngine(pipe_, metric=R.OracleLPIPS(7), verbose=False) if name == "oracle" else BlendingEngine(pipe_, verbose=False, frontier_width=4)
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=5)
+        (o.noise if name == "oracle" else tape).reset()
+        trees = []
+        segs = replay.run_multi_transition(be, prompts, seeds, None, pipeline_keyframes=True,
+                                           on_segment=lambda i, fr: trees.append((list(be.tree_fracts), list(be.tree_idx_injection))))
+        res[name] = {"segs": [[np.asarray(f).astype(np.int32) for f in seg] for seg in segs], "trees": trees,
+                     "last": be.tree_latents[-1][-1].float().cpu(), "pre": be.stats.get("keyframes_precomputed")}
+    set_backend(None)
+    a, b = res["native"], res["oracle"]
+    assert a["pre"] == b["pre"] == 3 and a["trees"] == b["trees"], (a["trees"], b["trees"])
+    assert np.array_equal(a["segs"][1][0], a["segs"][0][-1])
+    d = [float(np.stack([np.abs(x - y) for x, y in zip(sa, sb)]).mean()) for sa, sb in zip(a["segs"], b["segs"])]
+    err = rel_l2(a["last"], b["last"])
+    results_log["pipelined_keyframe_chain"] = {"frames": [len(s_) for s_ in a["segs"]], "mean_abs_u8": d, "final_latent_rel_l2": err}
+    assert max(d) <= 2 and err <= 3e-2
+
+
 def test_frontier_equals_sequential(results_log):
     """Speculative batched frontier commits exactly the sequential greedy tree (same native pipe)."""
     from latentblending_amd import BlendingEngine
