@@ -250,7 +250,7 @@ def roofline_blocks(prof, launch_counts, device):
     a = _tf(prof["attn_flops"], prof["attn_ms"])
     gn = _gbs(prof["gn_bytes"], prof["gn_ms"])
     rest = [
-        {"kernel": "attn_fwd_d64_kernel<KT,QG,NS> (UNet self + cross attention, in situ)", "bound": "mfma", "achieved": a,
+        {"kernel": "attn_fwd_d64_kernel<KT,QG,NS> (UNet self + cross attention) + attn_fwd_d512_kernel (VAE mid block), in situ", "bound": "mfma", "achieved": a,
          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F16_PEAK_TFLOPS,
          "per_transition": {"tflop": prof["attn_flops"] / 1e12, "ms": prof["attn_ms"], "launches": prof["attn_launches"],
                             "self_TFLOPs": _tf(prof["attn_self_flops"], prof["attn_self_ms"]), "self_ms": prof["attn_self_ms"],

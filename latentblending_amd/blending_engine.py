@@ -77,6 +77,8 @@ class BlendingEngine:
         #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
+        self.fuse_recycled_anchor = True    # ... also when an anchor is recycled (swap_forward chains, precomputed key frames): the
+        #                                     fused wavefront takes the stored trajectory as given and denoises only the other one
         self.host_frames = False            # True: run_transition hands back HOST PIL images (the reference's return type in full): one
         #                                     device->host copy of all frames through a pinned buffer + their PIL cores, ~1.6 ms per
         #                                     17-frame transition; False (default): lazy DeviceImage frames, copied when first touched.
@@ -285,12 +287,13 @@ class BlendingEngine:
         prefilled = None
         restore_noise = self._farm_begin(keep1, keep2) if self._farm_on() else None
         try:
+            recycled_ok = self.fuse_recycled_anchor and not self._farm_on()
             fuse = (use_frontier and self.fuse_anchor_round and _is_native(self.dh.pipe)
-                    and not keep1 and not keep2 and self.branch1_crossfeed_power == 0.0 and self.speculate_virtual
+                    and ((not keep1 and not keep2) or recycled_ok) and self.branch1_crossfeed_power == 0.0 and self.speculate_virtual
                     and len(self.list_idx_injection) == 1 and int(self.list_idx_injection[0]) >= 1
                     and int(self.list_nmb_stems[0]) >= 1 and self._uniform_cfg())
             if fuse:
-                first, last, prefilled = self._anchors_with_first_round()
+                first, last, prefilled = self._anchors_with_first_round(keep1, keep2)
             elif self._farm_on():
                 first, last = self._anchors_distributed(keep1, keep2)
             elif use_frontier and _is_native(self.dh.pipe) and not keep1 and not keep2 \
@@ -538,12 +541,14 @@ class BlendingEngine:
             level = nxt
         return out
 
-    def _anchors_with_first_round(self):
+    def _anchors_with_first_round(self, keep1=False, keep2=False):
         """Single-level trees on a native pipe: every mid branch mixes the two ANCHORS, and at step i
         it only needs their latents of step i-1.  So the first speculative round (level-order
         midpoints, exactly what the best-first frontier would pick before any distance is known) is
         denoised in the same UNet batches as the anchors' own steps >= idx_injection, all frames
-        are decoded in one batch, and the greedy loop then starts from a pre-filled pool."""
+        are decoded in one batch, and the greedy loop then starts from a pre-filled pool.
+        ``keep1`` / ``keep2``: that anchor is recycled (``tree_latents[0]`` / ``[-1]`` hold its trajectory): only the
+        other one is denoised; frames handed over by ``preset_anchors`` are used instead of decoding the anchors again."""
         pipe, steps = self.dh.pipe, self.num_inference_steps
         idx_injection, stems = int(self.list_idx_injection[0]), int(self.list_nmb_stems[0])
         self.dh.set_num_inference_steps(steps)
@@ -559,8 +564,13 @@ class BlendingEngine:
             [self.get_noise(self.seed1), self.get_noise(self.seed2)],
             [self.get_mixed_conditioning(gaps[k][2])[0] for k in mine], [gaps[k][2] for k in mine],
             [coeffs] * len(mine), idx_injection, steps, self.guidance_scale, [guid[k] for k in mine],
-            noise_slots=(len(gaps), mine) if farm else None, elide_dead_steps=self.elide_dead_steps and not farm)
-        if farm and farm.rank != 0:
+            noise_slots=(len(gaps), mine) if farm else None, elide_dead_steps=self.elide_dead_steps and not farm,
+            known_anchors=(self.tree_latents[0] if keep1 else None, self.tree_latents[-1] if keep2 else None))
+        self.tree_latents[0], self.tree_latents[-1] = first, last       # (what compute_latents1 / 2 leave behind)
+        preset, self._preset_anchor_frames = self._preset_anchor_frames, None
+        if preset is not None and not farm:
+            frames = list(preset) + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])
+        elif farm and farm.rank != 0:
             # the anchors' FRAMES come from rank 0 in the broadcast below: only their owner decodes them (at 8 ranks the
             # decode batch of a non-owner halves: 2 mid frames instead of 2 + 2)
             frames = [None, None] + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])

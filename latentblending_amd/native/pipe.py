@@ -385,7 +385,8 @@ class StableDiffusionXLPipeline:
                              mid_conds: Sequence[tuple], mid_fracts: Sequence[float],
                              mid_coeffs: Sequence[Sequence[float]], idx_injection: int, num_inference_steps: int,
                              guidance_anchor: float, guidance_mids: Sequence[float],
-                             noise_slots: Optional[Tuple[int, Sequence[int]]] = None, elide_dead_steps: bool = False):
+                             noise_slots: Optional[Tuple[int, Sequence[int]]] = None, elide_dead_steps: bool = False,
+                             known_anchors: Sequence[Optional[Sequence[torch.Tensor]]] = (None, None)):
         """Both anchors AND a set of mid branches whose parents are the anchors, in one wavefront.
 
         A mid branch at step i only needs the anchors' latents of step i-1 (its start latent and its
@@ -400,18 +401,28 @@ class StableDiffusionXLPipeline:
         completely (crossfeed coefficient exactly 1.0 - the SDXL-Turbo defaults, reference blending_engine.py:193-199,
         452-457 and diffusers_holder.py:322-324: slerp(x, target, 1.0) == target) is not computed: that step runs the
         anchors only, the mids' trajectory entry is ``None``.  Frames and final latents are bit-identical (noise draws
-        are still consumed in the same order); the reference itself performs the dead forward, so the default is off."""
-        A, G = 2, len(mid_conds)
+        are still consumed in the same order); the reference itself performs the dead forward, so the default is off.
+        ``known_anchors[k]`` = a finished trajectory of anchor k (a recycled key frame, blending_engine.py:333-342 of the
+        reference: ``recycle_img1`` after ``swap_forward``): that anchor is not denoised again - the small batches carry only
+        the other anchor, the mids mix from the stored latents - and is returned as given."""
+        known = [None if t is None else list(t) for t in known_anchors]
+        live = [k for k in (0, 1) if known[k] is None]          # anchors denoised here
+        A, G = len(live), len(mid_conds)
+        assert A + G > 0, "native_run_wavefront: nothing to denoise"
+        assert all(t is None or len(t) == num_inference_steps for t in known), "known anchors must be full trajectories"
+        anchor_conds = [anchor_conds[k] for k in live]
         sched, steps = self.scheduler, num_inference_steps
         if sched.num_inference_steps != steps:
             sched.set_timesteps(steps)
         all_g = [float(guidance_anchor)] * A + [float(g) for g in guidance_mids]
         self._guidance_scale = all_g[-1]
         cfg = self.uses_cfg(all_g[0])
+        ref_start = anchor_starts[0]
+        anchor_starts = [anchor_starts[k] for k in live]
         assert all(self.uses_cfg(g) == cfg for g in all_g), "wavefront batches must be uniformly CFG or non-CFG"
         mul = 2 if cfg else 1
-        L = anchor_starts[0].shape[-1]
-        per_sample = anchor_starts[0][0].numel()
+        L = ref_start.shape[-1]
+        per_sample = ref_start[0].numel()
 
         def conditioning(conds):
             pos_ctx = torch.cat([c[0] for c in conds]).to(self.device, F16)
@@ -432,25 +443,27 @@ class StableDiffusionXLPipeline:
         # G == 0: a farm rank that owns no mid branch of the round (fewer gaps than ranks) still runs both anchors
         dead = [bool(elide_dead_steps) and G > 0 and i >= idx_injection and i + 1 < steps and
                 all(float(mid_coeffs[g][i + 1]) == 1.0 for g in range(G)) for i in range(steps)]
-        prog_a = prepared(list(anchor_conds)) if (idx_injection > 0 or G == 0 or any(dead)) else None
+        prog_a = prepared(list(anchor_conds)) if A and (idx_injection > 0 or G == 0 or any(dead)) else None
         prog_all = prepared(list(anchor_conds) + list(mid_conds)) if G else prog_a
         stream = torch.cuda.current_stream().cuda_stream
         rows_a = [sched.step_row(i, all_g[0]) for i in range(steps)]
-        par_a = ops.step_params([r for r in rows_a for _ in range(A)], self.device).view(steps, A, 8)
+        par_a = ops.step_params([r for r in rows_a for _ in range(A)], self.device).view(steps, A, 8) if A else None
         par_all = ops.step_params([sched.step_row(i, all_g[s]) for i in range(idx_injection, steps)
                                    for s in range(A + G)], self.device).view(-1, A + G, 8) if G else None
-        shape1 = (1,) + tuple(anchor_starts[0].shape[1:])
+        shape1 = (1,) + tuple(ref_start.shape[1:])
         noise_a = noise_m = None
-        if sched.ancestral:       # sample-major draws: anchor 1, anchor 2, then every mid branch
+        if sched.ancestral:       # sample-major draws: anchor 1, anchor 2 (those denoised here), then every mid branch
             noise_a = torch.stack([torch.cat([sched.draw_noise(shape1, self.device) for _ in range(steps)])
-                                   for _ in range(A)], dim=1)
+                                   for _ in range(A)], dim=1) if A else None
             n_draw, keep = (G, list(range(G))) if noise_slots is None else (int(noise_slots[0]), list(noise_slots[1]))
             drawn = [torch.cat([sched.draw_noise(shape1, self.device) for _ in range(idx_injection, steps)])
                      for _ in range(n_draw)]
             noise_m = torch.stack([drawn[k] for k in keep], dim=1) if G else None
-        lat_a = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in anchor_starts]).contiguous()
+        lat_shape = (int(ref_start.shape[-3]), L, L)
+        lat_a = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in anchor_starts]).contiguous() if A else \
+            torch.empty((0,) + lat_shape, dtype=F16, device=self.device)
         lat_m = None
-        traj_a = [[], []]
+        traj_a = [[] if known[k] is None else [t.to(self.device, F16).reshape(1, -1, L, L) for t in known[k]] for k in (0, 1)]
         traj_m: List[List[Optional[torch.Tensor]]] = [[None] * idx_injection for _ in range(G)]
         # mixing fractions / crossfeed coefficients live on the device: every step's parental mix (ONE pair of anchor
         # latents at G fractions) and crossfeed (G pairs) is one strided-slerp launch, no host pointer tables
@@ -460,29 +473,36 @@ class StableDiffusionXLPipeline:
                                 dtype=torch.float64, device=self.device) if G else None
         for i in range(steps):
             if i < idx_injection or G == 0 or dead[i]:
-                prog, lat, params, n = prog_a, lat_a, par_a[i], A
-                noise = noise_a[i] if noise_a is not None else None
                 if dead[i] and i == idx_injection:
                     # the mids' (never denoised) start value: the parental mix of step i-1, exactly what the live path starts
                     # from - the next step's crossfeed slerp at coefficient 1.0 replaces it bit for bit, but its FIRST operand
                     # must be a proper latent (a zero tensor has no direction: 0 / 0 in the slerp's cosine)
                     lat_m = ops.slerp_strided(traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous(), fr_dev, n_lat,
-                                              broadcast0=True, broadcast1=True).view(G, *lat_a.shape[1:])
+                                              broadcast0=True, broadcast1=True).view(G, *lat_shape)
                     self.stats["slerps"] += G
+                if A == 0:                  # both anchors known: nothing runs before the injection step (or in a dead one)
+                    if i >= idx_injection and G and dead[i]:
+                        for g in range(G):
+                            traj_m[g].append(None)
+                    continue
+                prog, lat, params, n = prog_a, lat_a, par_a[i], A
+                noise = noise_a[i] if noise_a is not None else None
             else:
                 prev1, prev2 = traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous()
                 mix_prev = ops.slerp_strided(prev1, prev2, fr_dev, n_lat, broadcast0=True, broadcast1=True)   # parental mix of step i-1
                 self.stats["slerps"] += G
                 if i == idx_injection:
-                    lat_m = mix_prev.view(G, *lat_a.shape[1:])
+                    lat_m = mix_prev.view(G, *lat_shape)
                 elif dead[i - 1]:
                     assert all(float(mid_coeffs[g][i]) == 1.0 for g in range(G))
                 nfeed = sum(1 for g in range(G) if mid_coeffs[g][i] > 0)
                 if nfeed:       # (a coefficient of 0 returns the first operand bit-exactly, like the reference's skipped slerp)
-                    lat_m = ops.slerp_strided(lat_m.contiguous().view(G, n_lat), mix_prev, coef_dev[i], n_lat).view(G, *lat_a.shape[1:])
+                    lat_m = ops.slerp_strided(lat_m.contiguous().view(G, n_lat), mix_prev, coef_dev[i], n_lat).view(G, *lat_shape)
                     self.stats["slerps"] += nfeed
-                prog, lat, params, n = prog_all, torch.cat([lat_a, lat_m]), par_all[i - idx_injection], A + G
-                noise = torch.cat([noise_a[i], noise_m[i - idx_injection]]) if noise_a is not None else None
+                prog, lat, params, n = prog_all, (torch.cat([lat_a, lat_m]) if A else lat_m.contiguous()), par_all[i - idx_injection], A + G
+                noise = None
+                if noise_m is not None:
+                    noise = torch.cat([noise_a[i], noise_m[i - idx_injection]]) if A else noise_m[i - idx_injection]
             api.lb_scale_model_input_f16(lat.data_ptr(), prog.x_in.data_ptr(), params.data_ptr(), per_sample, n,
                                          int(cfg), stream)
             prog.tvals.fill_(float(sched.timesteps_np[i]))
@@ -491,8 +511,8 @@ class StableDiffusionXLPipeline:
             self.stats["unet_samples"] += prog.B
             out = ops.euler_step(lat, prog.eps, params, noise=noise, cfg=cfg, ancestral=sched.ancestral)
             lat_a = out[:A]
-            traj_a[0].append(out[0:1])
-            traj_a[1].append(out[1:2])
+            for j, k in enumerate(live):
+                traj_a[k].append(out[j:j + 1])
             if i >= idx_injection and G and dead[i]:
                 for g in range(G):
                     traj_m[g].append(None)

@@ -226,6 +226,50 @@ def test_chained_transitions_match_oracle(results_log):
     assert d1.mean() <= 2 and d2.mean() <= 2 and err <= 3e-2
 
 
+def test_recycled_anchor_goes_through_the_fused_wavefront(results_log):
+    """swap_forward + run_transition(recycle_img1=True) in frontier mode: the fused wavefront takes the recycled anchor's stored
+    trajectory as given (known_anchors) and denoises only the new one - small batches of 1, large ones of 1 + G.  Against the
+    unfused path on the same pipe (same noise tape: same draws in the same order) the trees are equal and the frames differ
+    only by batch-composition rounding; against the sequential oracle engine they are within the model tolerance."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    o, p, tape = make_pair(turbo=True)
+    runs = {}
+    for name in ("oracle", "unfused", "fused"):
+        set_backend(R.TorchCpuBackend() if name == "oracle" else None)
+        np.random.seed(0)
+        if name == "oracle":
+            be = BlendingEngine(o, metric=R.OracleLPIPS(7), verbose=False)
+        else:
+            be = BlendingEngine(p, verbose=False, frontier_width=4)
+            be.fuse_recycled_anchor = name == "fused"
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=5)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        (o.noise if name == "oracle" else tape).reset()
+        before = p.stats["unet_samples"]
+        be.run_transition(fixed_seeds=[420, 421])
+        mid = p.stats["unet_samples"]
+        be.swap_forward()
+        be.set_prompt2("a forest in the fog")
+        second = be.run_transition(recycle_img1=True, fixed_seeds=[421, 999])
+        runs[name] = {"frames": [np.asarray(i).astype(np.int32) for i in second], "tree": (list(be.tree_fracts), list(be.tree_idx_injection)),
+                      "last": be.tree_latents[-1][-1].float().cpu(), "first": be.tree_latents[0][-1].float().cpu(),
+                      "samples": p.stats["unet_samples"] - mid, "samples_first": mid - before}
+    set_backend(None)
+    f, u, orc = runs["fused"], runs["unfused"], runs["oracle"]
+    assert f["tree"] == u["tree"] == orc["tree"], (f["tree"], u["tree"], orc["tree"])
+    assert f["samples"] == u["samples"]                                  # the same forwards, batched differently
+    assert torch.equal(f["first"], u["first"])                           # the recycled trajectory is handed through untouched
+    d_fu = float(np.stack([np.abs(a - b) for a, b in zip(f["frames"], u["frames"])]).mean())
+    d_fo = float(np.stack([np.abs(a - b) for a, b in zip(f["frames"], orc["frames"])]).mean())
+    err = rel_l2(f["last"], orc["last"])
+    results_log["recycled_anchor_fused"] = {"mean_abs_u8_vs_unfused": d_fu, "mean_abs_u8_vs_oracle": d_fo, "final_latent_rel_l2": err,
+                                            "unet_samples_second_transition": f["samples"]}
+    assert d_fu <= 1 and d_fo <= 2 and err <= 3e-2
+
+
 def test_pipelined_keyframe_chain_matches_oracle(results_log):
     """replay.run_multi_transition(pipeline_keyframes=True): the native engine denoises all key frames as ONE lock-step batch
     (native_run_diffusion_batch, noise drawn sample-major) and decodes them in one VAE batch; the same driver over the CPU

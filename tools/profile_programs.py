@@ -68,7 +68,7 @@ def main():
             print(f"   hipGraph replay: {(time.perf_counter() - t0) * 100:.3f} ms per forward (B={B})", file=fh)
             vp = pipe.vae_program(B, 64)
             vp.decode(torch.randn(B, 4, 64, 64, device="cuda").half())
-            table(vp.prog, vp.em.gemm_log, [], f"VAE decode program B={B} L=64", fh)
+            table(vp.prog, vp.em.gemm_log, vp.em.attn_log, f"VAE decode program B={B} L=64", fh)
             vp.prog.instantiate()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
