@@ -146,6 +146,52 @@ def gemm_family_profile(pipe, launches):
     return tot
 
 
+def phase_split(pipe, be):
+    """SURVEY.md §8(d) "per-phase split": ONE more transition with hipEvent pairs around every UNet step program launch, every
+    VAE program launch and every perceptual-distance call (graph replays, in situ), and the host copy timed on the host.
+    "mixing_and_gaps" is the remainder: slerp / crossfeed / scale / Euler kernels between the programs plus launch gaps."""
+    from latentblending_amd.native.frames import materialise_frames
+    spans = {"unet": [], "vae": [], "lpips": []}
+    undo = []
+
+    def wrap(obj, name, key):
+        orig = getattr(obj, name)
+
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            spans[key].append((e0, e1))
+            return r
+        setattr(obj, name, timed)
+        undo.append((obj, name, orig))
+    for prog in pipe._unet_programs.values():
+        wrap(prog.prog_step, "launch", "unet")
+    for prog in pipe._vae_programs.values():
+        wrap(prog.prog, "launch", "vae")
+    wrap(pipe, "native_frame_distances", "lpips")
+    try:
+        host_frames, be.host_frames = be.host_frames, False
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        materialise_frames(imgs)
+        t2 = time.perf_counter()
+    finally:
+        be.host_frames = host_frames
+        for obj, name, orig in undo:
+            setattr(obj, name, orig)
+    ms = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in spans.items()}
+    total = (t1 - t0) * 1e3
+    return {"unet_ms": ms["unet"], "vae_ms": ms["vae"], "lpips_ms": ms["lpips"], "host_frames_ms": (t2 - t1) * 1e3,
+            "mixing_and_gaps_ms": total - ms["unet"] - ms["vae"] - ms["lpips"], "transition_ms_without_host_copy": total,
+            "launches": {k: len(v) for k, v in spans.items()},
+            "note": "hipEvents around the program launches (graph replays) of one extra transition; comm = 0 at N = 1"}
+
+
 def install_launch_counters(pipe, counts):
     """Wrap the launch method of every recorded UNet step / VAE program so that `counts` ends up holding
     {("unet"|"vae", B, L): launches}.  A dict increment per PROGRAM launch (5 per transition): not measurable."""
@@ -573,8 +619,13 @@ def _run():
         torch.cuda.synchronize()
 
     frames = 0
-    for _ in range(args.warmup):
+    cold_start_s = None
+    for w in range(args.warmup):
+        tw = time.perf_counter()
         frames = len(be.run_transition(fixed_seeds=[420, 421]))
+        if w == 0:          # the first transition records the launch programs, captures their graphs and runs them once
+            torch.cuda.synchronize()
+            cold_start_s = time.perf_counter() - tw
     for k in pipe.stats:
         pipe.stats[k] = 0
     be.stats.clear()
@@ -630,8 +681,14 @@ def _run():
                        "collectives_per_transition": farm.collectives / max(args.steps + args.warmup, 1),
                        "bytes_moved_per_transition": farm.bytes_moved / max(args.steps + args.warmup, 1),
                        "ms_per_transition_by_rank": per_rank_ms},
-                   "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1)},
+                   "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1),
+                   "cold_start_s": None if cold_start_s is None else round(cold_start_s, 2)},
     }
+    if rank == 0 and world == 1 and not args.no_roofline:
+        try:
+            out["phases_per_transition"] = phase_split(pipe, be)
+        except Exception as exc:
+            out["phases_error"] = repr(exc)
     if rank == 0 and world == 1 and not args.no_roofline:      # (needs a solo transition: no collectives)
         # launches of every (program, batch) per transition: one more transition with counting wrappers
         step_launch_counts = {}

@@ -2,6 +2,7 @@
 # Same-box A/B of the round-2 tree (git archive 183f997 unpacked into _ab_r02/, not committed) against HEAD: fresh gpurun boxes
 # differ by 2-3 % in sustained clocks, so numbers of different calls cannot be compared.  Usage (repo root, GPU box):
 #   bash tools/ab_r02_vs_head.sh > gpurun_out/ab_r02_vs_head.txt
+# Prepare the comparison tree HERE first (the snapshot gpurun ships has no .git):  mkdir _ab_r02 && git archive 183f997 | tar -x -C _ab_r02
 R=$PWD
 export LB_SYNTH_CACHE=/tmp
 (cd $R/_ab_r02 && python __graft_entry__.py > /tmp/ab_build.log 2>&1; tail -1 /tmp/ab_build.log)
