@@ -20,6 +20,7 @@ State-dict key names follow the HF diffusers layout so real checkpoints could be
 from __future__ import annotations
 
 import math
+import os
 import zlib
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Tuple
@@ -81,9 +82,40 @@ def tiny_vae_cfg() -> VAECfg:
 # =============================================================================================
 # synthetic weights (HF key layout)
 # =============================================================================================
+_BIG = 3 << 19        # tensors above this many elements (1.57 M: the 1280 x 1280 projections and up; the tiny test models
+#                       stop at 1.18 M) take the chunked numpy path
+_CHUNK = 1 << 18
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(16, os.cpu_count() or 1)))
+    return _POOL
+
+
 def _gen(name: str, shape, std: float, seed: int, mean: float = 0.0) -> Tensor:
-    g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
-    return torch.randn(shape, generator=g, dtype=torch.float32) * std + mean
+    """N(mean, std^2) values from a seed that depends only on (name, seed).  Tensors up to 1.5 * 2^20 elements: one torch CPU
+    generator (the scheme every golden fixture was made with).  Larger ones (only the full-size SDXL / CLIP models have them;
+    2.6 G values took 76 s of one core per process): 2^18-element chunks, each from its own numpy PCG64 stream, filled by a
+    small thread pool (numpy releases the GIL) - same values whatever the thread count."""
+    base = (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF
+    shape = tuple(int(v) for v in shape)
+    n = 1
+    for v in shape:
+        n *= v
+    if n <= _BIG:
+        g = torch.Generator().manual_seed(base)
+        return torch.randn(shape, generator=g, dtype=torch.float32) * std + mean
+    buf = np.empty(n, dtype=np.float32)
+
+    def fill(c):
+        lo, hi = c * _CHUNK, min(n, (c + 1) * _CHUNK)
+        np.random.Generator(np.random.PCG64([base, c])).standard_normal(hi - lo, dtype=np.float32, out=buf[lo:hi])
+    list(_pool().map(fill, range((n + _CHUNK - 1) // _CHUNK)))
+    return torch.from_numpy(buf).view(shape).mul_(std).add_(mean)
 
 
 class _Spec:

@@ -8,6 +8,8 @@ import json
 import os
 import re
 
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -537,6 +539,22 @@ def test_pipelined_keyframes_chain_equals_the_sequential_chain(cpu_backend):
     be2.set_branch1_crossfeed(0.3, 0.5, 0.5)
     with pytest.raises(AssertionError):
         replay.run_multi_transition(be2, prompts, seeds, None, pipeline_keyframes=True)
+
+
+def test_synthetic_weight_streams_are_the_same_on_both_sides():
+    """The product's SyntheticProvider and the oracle's make_weights must draw the same values for the same (name, seed) - tiny
+    tensors from the single torch stream the golden fixtures were made with, big ones (> 1.5 * 2^20 elements) from the chunked
+    numpy streams - whatever the thread count."""
+    from latentblending_amd.native import weights as W
+    for shape in [(7,), (64, 64), (256, 512, 3, 3), (1280, 1280), (1280, 1280, 3, 3)]:
+        a, b = R._gen("mid_block.x.weight", shape, 0.03, 5, 0.5), W._seeded("mid_block.x.weight", shape, 0.03, 5, 0.5)
+        assert torch.equal(a, b) and a.shape == tuple(shape)
+        assert abs(float(a.mean()) - 0.5) < 0.02 and abs(float(a.std()) - 0.03) < 0.004
+    g = torch.Generator().manual_seed((zlib.crc32(b"mid_block.x.weight") ^ (5 * 0x9E3779B1)) & 0x7FFFFFFF)
+    assert torch.equal(W._seeded("mid_block.x.weight", (64, 64), 0.03, 5), torch.randn((64, 64), generator=g) * 0.03)    # the legacy stream
+    big = W._seeded("a", (1280, 1280), 1.0, 0)
+    assert not torch.equal(big, W._seeded("a", (1280, 1280), 1.0, 1)) and not torch.equal(big, W._seeded("b", (1280, 1280), 1.0, 0))
+    assert abs(float((big[:640] * big[640:]).mean())) < 0.01                      # chunks are independent streams
 
 
 def test_gemm_tile_policy_is_pinned():
