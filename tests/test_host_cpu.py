@@ -549,7 +549,8 @@ def test_synthetic_weight_streams_are_the_same_on_both_sides():
     for shape in [(7,), (64, 64), (256, 512, 3, 3), (1280, 1280), (1280, 1280, 3, 3)]:
         a, b = R._gen("mid_block.x.weight", shape, 0.03, 5, 0.5), W._seeded("mid_block.x.weight", shape, 0.03, 5, 0.5)
         assert torch.equal(a, b) and a.shape == tuple(shape)
-        assert abs(float(a.mean()) - 0.5) < 0.02 and abs(float(a.std()) - 0.03) < 0.004
+        if a.numel() >= 4096:
+            assert abs(float(a.mean()) - 0.5) < 0.005 and abs(float(a.std()) - 0.03) < 0.002
     g = torch.Generator().manual_seed((zlib.crc32(b"mid_block.x.weight") ^ (5 * 0x9E3779B1)) & 0x7FFFFFFF)
     assert torch.equal(W._seeded("mid_block.x.weight", (64, 64), 0.03, 5), torch.randn((64, 64), generator=g) * 0.03)    # the legacy stream
     big = W._seeded("a", (1280, 1280), 1.0, 0)
