@@ -187,7 +187,8 @@ int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
  * no S x S score matrix exists (the three-launch form scores GEMM -> lb_softmax_rows_f16 -> PV GEMM wrote 32 MB per sample at 512^2,
  * 512 MB at 1024^2) */
 int lb_attn_fwd_d512(const LbAttnParams* params, void* stream);
-void lb_attn_set_tuning(int force);   /* testing: 0 = by shape; bits 0-1 = query groups per wave (1 / 2), bit 4 = always stream 64-key tiles */
+void lb_attn_set_tuning(int force);   /* testing: 0 = by shape; bits 0-1 = query groups per wave (1 / 2), bit 4 = always stream 64-key tiles,
+                                       * bit 5 = 5-stage ring for the streaming form (A/B knob) */
 int lb_softmax_rows_f16(void* x, int M, int N, int ld, float scale, void* stream);
 
 /* ---- small kernels ----------------------------------------------------------------- */

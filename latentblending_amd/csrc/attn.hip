@@ -289,11 +289,19 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
 template <int KT, int QG, int NS>
 static void attn_launch(const LbAttnParams& p, hipStream_t s) {
     const size_t smem = (size_t)NS * 2 * KT * ATT_D * sizeof(f16);
+    if constexpr (NS * 2 * KT * ATT_D * sizeof(f16) > 64 * 1024) {      // (beyond the default dynamic-LDS limit: the 5-stage A/B form)
+        static bool allowed = false;
+        if (!allowed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_d64_kernel<KT, QG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            allowed = true;
+        }
+    }
     const dim3 grid((p.Sq + 64 * QG - 1) / (64 * QG), p.H, p.B);
     hipLaunchKernelGGL((attn_fwd_d64_kernel<KT, QG, NS>), grid, dim3(256), smem, s, p);
 }
 
-// variant (testing): 0 = by shape, else bit 0..1 QG (1 / 2), bit 4 forces the 64-key streaming tile
+// variant (testing): 0 = by shape, else bit 0..1 QG (1 / 2), bit 4 forces the 64-key streaming tile, bit 5 = a 5-stage ring for the
+// streaming form (80 KiB: a sequence of <= 256 keys is then requested whole in the prologue; A/B knob, not a default)
 static int g_attn_force = 0;
 extern "C" void lb_attn_set_tuning(int force) { g_attn_force = force; }
 
@@ -303,6 +311,7 @@ static int attn_dispatch(const LbAttnParams& p, int force, hipStream_t s) {
     int qg = force & 3;
     if (qg == 0) qg = (long)((p.Sq + 127) / 128) * p.H * p.B >= 384 ? 2 : 1;   // 128-row blocks once they fill the chip
     if (single) { if (qg == 2) attn_launch<96, 2, 2>(p, s); else attn_launch<96, 1, 2>(p, s); }
+    else if (force & 32) { if (qg == 2) attn_launch<64, 2, 5>(p, s); else attn_launch<64, 1, 5>(p, s); }
     else        { if (qg == 2) attn_launch<64, 2, 3>(p, s); else attn_launch<64, 1, 3>(p, s); }
     return lb_check_launch("lb_attn_fwd_d64");
 }

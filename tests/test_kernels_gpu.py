@@ -445,7 +445,8 @@ def test_attention_d64(case, results_log):
     check_close(results_log, f"attn_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
 
 
-@pytest.mark.parametrize("force", [1, 2, 17, 18])
+# (49 / 50 = bit 5: the 5-stage-ring A/B form added at the end of round 3 without a GPU run: opt in with LB_TEST_EXPERIMENTAL=1)
+@pytest.mark.parametrize("force", [1, 2, 17, 18] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
 @pytest.mark.parametrize("case", [(2, 3, 300, 300, 300), (2, 2, 130, 80, 77), (1, 2, 70, 96, 90), (1, 1, 16, 8, 5)])
 def test_attention_d64_variants(case, force, results_log):
     """Every kernel variant (1 / 2 query groups per wave, single 96-key tile / streamed 64-key tiles) on ragged shapes,
