@@ -449,6 +449,8 @@ class BlendingEngine:
                         noise_slots=(n, mine) if farm else None)
                     for k, t in zip(mine, got):
                         trajs[k] = t
+                elif ancestral:          # fewer key frames than ranks: a rank without one still advances a shared noise stream
+                    self._skip_noise_draws(n * steps)
             else:
                 for k in range(n):                       # (generic pipes: one trajectory at a time, in chain order)
                     if k in mine:
