@@ -11,6 +11,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-size SDXL models against the CPU fp32 oracle (minutes of host time); "
+                                       "`-m \"gpu and not slow\"` is the quick loop, the driver runs everything")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 
 from oracle import pipe as OP  # noqa: E402  (checker only)
 from oracle import sdxl_ref as R  # noqa: E402

@@ -327,6 +327,7 @@ def test_frontier_equals_sequential(results_log):
     assert d.mean() <= 1.0
 
 
+@pytest.mark.slow
 def test_full_size_sdxl_unet_and_vae(results_log):
     """BASELINE shapes: full SDXL UNet (2.57 B params) at B=1, 64x64 latent (512^2) and the full VAE
     decoder, against the CPU fp32 oracle with the same seeded weights."""
