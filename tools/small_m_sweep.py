@@ -1,7 +1,7 @@
 """Small-M (B = 2 anchor phase) GEMM study: (tile, ring stages, split-K) over the shapes of the B = 2 UNet step program,
 with COLD weights - every launch of the timed graph reads a different weight matrix (as the model does: 5.1 GB of
 weights per forward never stay in the 256 MB Infinity Cache), bias + residual epilogue as in situ.
-Usage (GPU box): python tools/small_m_sweep.py > gpurun_out/small_m_sweep.txt"""
+Usage (GPU box): python tools/small_m_sweep.py > gpurun_out/small_m_sweep.txt   (LB_SWEEP_SET=b17: the B = 17 shapes, LB_SWEEP_NW=24)"""
 import ctypes as C
 import os
 import sys
@@ -45,6 +45,10 @@ def main():
     shapes = [("lin", 512, 1280, 1280), ("lin", 512, 1280, 5120), ("lin", 512, 3840, 1280), ("geglu", 512, 10240, 1280),
               ("lin", 2048, 640, 640), ("lin", 2048, 640, 2560), ("lin", 2048, 1920, 640), ("geglu", 2048, 5120, 640),
               ("lin", 8192, 320, 640), ("lin", 512, 1280, 2560), ("conv", 512, 1280, 11520), ("conv", 2048, 640, 5760)]
+    if os.environ.get("LB_SWEEP_SET") == "b17":     # the B = 17 programs' shapes that run on 128-wide tiles or the 192x128 one: does a deeper
+        # ring pay once every CU is busy?  ("open hypothesis"; tiles 4 / 5 / 7 have fixed depths and are the `auto` column)
+        shapes = [("lin", 4352, 1280, 1280), ("lin", 17408, 640, 640), ("lin", 17408, 1920, 640), ("lin", 17408, 640, 2560),
+                  ("lin", 4352, 1280, 5120), ("lin", 4352, 3840, 1280), ("lin", 69632, 320, 640)]
     if len(sys.argv) > 1:
         shapes = [s for s in shapes if f"{s[1]}x{s[2]}x{s[3]}" in sys.argv[1:]]
     zp = torch.zeros(64, dtype=torch.uint8, device=DEV)
