@@ -81,12 +81,10 @@ def respawn_under_torchrun(args):
     so the driver's plain command and its explicit torchrun command are the same job.  Never returns when it re-executes."""
     if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun itself picks AND HOLDS a free rendezvous port (binding port 0 here and closing the socket
+    # before exec left a window in which another process could take the port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-executing under torch.distributed.run\n")
     sys.stderr.flush()
     os.execv(sys.executable, cmd)

@@ -89,6 +89,7 @@ class BlendingEngine:
         #                                     exactly 1.0, the Turbo defaults) overwrites completely - bit-identical frames, fewer
         #                                     UNet forwards than the reference performs; tree_latents entries of the
         #                                     skipped steps are None
+        self.keyframe_chunk = 16            # precompute_keyframes / batched decodes: at most this many samples per UNet / VAE batch
         self.seed1 = 0
         self.seed2 = 0
         self.prompt1 = ""
@@ -104,6 +105,7 @@ class BlendingEngine:
         self.negative_prompt = None
         self.stats = {}
         self._preset_anchor_frames = None      # (frame of anchor 1, frame of anchor 2) for the next transition: see preset_anchors
+        self._anchor_frames_given = (None, None)    # ... the ones of them that belong to anchors really recycled in the running call
 
         self.set_guidance_scale()
         self.multi_transition_img_first = None
@@ -284,6 +286,11 @@ class BlendingEngine:
         use_frontier = self.frontier_width > 1 or self.farm is not None
         keep1 = recycle_img1 and len(self.tree_latents[0]) == steps
         keep2 = recycle_img2 and len(self.tree_latents[-1]) == steps
+        # frames handed over by preset_anchors belong to the trajectories it installed: an anchor that is denoised again
+        # in this call must be decoded again too (and a preset must never outlive the call it was made for)
+        preset, self._preset_anchor_frames = self._preset_anchor_frames, None
+        self._anchor_frames_given = (preset[0] if preset is not None and keep1 else None,
+                                     preset[1] if preset is not None and keep2 else None)
         prefilled = None
         restore_noise = self._farm_begin(keep1, keep2) if self._farm_on() else None
         try:
@@ -314,9 +321,11 @@ class BlendingEngine:
     def _grow_tree(self, first, last, prefilled, use_frontier):
 
         if prefilled is None:
-            frames, self._preset_anchor_frames = self._preset_anchor_frames, None
-            if frames is None:
-                frames = self._decode_many([first[-1], last[-1]])
+            frames = list(self._anchor_frames_given)
+            todo = [k for k in (0, 1) if frames[k] is None]
+            if todo:
+                for k, f in zip(todo, self._decode_many([(first, last)[k][-1] for k in todo])):
+                    frames[k] = f
             self._tree.reset(first, last, frames[0], frames[1])
 
         for level in tqdm(range(len(self.list_idx_injection)), disable=not self.verbose):
@@ -443,12 +452,19 @@ class BlendingEngine:
             if _is_native(pipe):
                 if mine:
                     zeros = [0.0] * steps
-                    got = pipe.native_run_diffusion_batch(
-                        [embeddings[k] for k in mine], [self.get_noise(int(seeds[k])) for k in mine], 0, [None] * len(mine),
-                        [zeros] * len(mine), num_inference_steps=steps, guidance_scales=[self.guidance_scale] * len(mine),
-                        noise_slots=(n, mine) if farm else None)
-                    for k, t in zip(mine, got):
-                        trajs[k] = t
+                    # bounded program shapes: a long chain is denoised in chunks of ``keyframe_chunk`` key frames (one UNet
+                    # program per distinct batch size stays cached with its arena).  Ancestral noise is drawn sample-major
+                    # by the batch call, so consecutive chunks consume a stream in the same order as one big batch; under
+                    # a farm a rank's share (n / world key frames) goes in one call (its noise slots span the whole round)
+                    width = len(mine) if farm else max(1, int(self.keyframe_chunk))
+                    for c0 in range(0, len(mine), width):
+                        part = mine[c0:c0 + width]
+                        got = pipe.native_run_diffusion_batch(
+                            [embeddings[k] for k in part], [self.get_noise(int(seeds[k])) for k in part], 0, [None] * len(part),
+                            [zeros] * len(part), num_inference_steps=steps, guidance_scales=[self.guidance_scale] * len(part),
+                            noise_slots=(n, part) if farm else None)
+                        for k, t in zip(part, got):
+                            trajs[k] = t
                 elif ancestral:          # fewer key frames than ranks: a rank without one still advances a shared noise stream
                     self._skip_noise_draws(n * steps)
             else:
@@ -473,6 +489,8 @@ class BlendingEngine:
     def preset_anchors(self, first, last, frame_first=None, frame_last=None):
         """Install two finished anchor trajectories (and, optionally, their decoded frames) for the next
         ``run_transition(recycle_img1=True, recycle_img2=True)``."""
+        assert len(first) == len(last) == self.num_inference_steps, \
+            "preset_anchors: both trajectories must have num_inference_steps entries"
         self.tree_latents[0], self.tree_latents[-1] = first, last
         self._preset_anchor_frames = (frame_first, frame_last) if frame_first is not None and frame_last is not None else None
 
@@ -525,7 +543,12 @@ class BlendingEngine:
 
     def _decode_many(self, latents: list):
         if _is_native(self.dh.pipe) and len(latents) > 1:
-            return self.dh.pipe.native_latent2image_batch(latents, "pil")
+            width = max(1, int(self.keyframe_chunk))        # bounded VAE program shapes / arenas (see precompute_keyframes)
+            out = []
+            for c0 in range(0, len(latents), width):
+                part = latents[c0:c0 + width]
+                out += self.dh.pipe.native_latent2image_batch(part, "pil") if len(part) > 1 else [self.dh.latent2image(part[0])]
+            return out
         return [self.dh.latent2image(z) for z in latents]
 
     # speculative frontier (native pipes) ---------------------------------------------------
@@ -569,9 +592,9 @@ class BlendingEngine:
             noise_slots=(len(gaps), mine) if farm else None, elide_dead_steps=self.elide_dead_steps and not farm,
             known_anchors=(self.tree_latents[0] if keep1 else None, self.tree_latents[-1] if keep2 else None))
         self.tree_latents[0], self.tree_latents[-1] = first, last       # (what compute_latents1 / 2 leave behind)
-        preset, self._preset_anchor_frames = self._preset_anchor_frames, None
-        if preset is not None and not farm:
-            frames = list(preset) + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])
+        given = self._anchor_frames_given
+        if given[0] is not None and given[1] is not None and not farm:
+            frames = list(given) + (pipe.native_latent2image_batch([t[-1] for t in mids], "pil") if mids else [])
         elif farm and farm.rank != 0:
             # the anchors' FRAMES come from rank 0 in the broadcast below: only their owner decodes them (at 8 ranks the
             # decode batch of a non-owner halves: 2 mid frames instead of 2 + 2)

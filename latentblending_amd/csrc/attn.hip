@@ -290,11 +290,9 @@ template <int KT, int QG, int NS>
 static void attn_launch(const LbAttnParams& p, hipStream_t s) {
     const size_t smem = (size_t)NS * 2 * KT * ATT_D * sizeof(f16);
     if constexpr (NS * 2 * KT * ATT_D * sizeof(f16) > 64 * 1024) {      // (beyond the default dynamic-LDS limit: the 5-stage A/B form)
-        static bool allowed = false;
-        if (!allowed) {
+        static unsigned long long seen = 0;
+        if (lb_first_call_on_device(seen))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_d64_kernel<KT, QG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            allowed = true;
-        }
     }
     const dim3 grid((p.Sq + 64 * QG - 1) / (64 * QG), p.H, p.B);
     hipLaunchKernelGGL((attn_fwd_d64_kernel<KT, QG, NS>), grid, dim3(256), smem, s, p);

@@ -377,9 +377,8 @@ static void allow_lds() {
 }
 
 void lb_gemm_glds_init() {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    static unsigned long long seen = 0;
+    if (!lb_first_call_on_device(seen)) return;
     allow_lds<128, 128, 2, 2>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
     allow_lds<128, 64, 2, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
     allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2>(); allow_lds<64, 64, 4>();

@@ -271,12 +271,10 @@ static int slerp_batched_impl(const void* p0, const void* p1, void* out, const d
     const int staged = stage_bytes <= 128 * 1024 ? 1 : 0;
     const size_t smem = 512 + (staged ? stage_bytes : 0);
     auto kern = slerp_batched_kernel<f16, 8>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long seen = 0;
+    if (lb_first_call_on_device(seen))
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 512 + 128 * 1024);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)npairs), dim3(512), smem, stream,
                        (const f16*)p0, (const f16*)p1, (f16*)out, fracts_dev, n, staged);
     return lb_check_launch("lb_slerp_batched_f16");

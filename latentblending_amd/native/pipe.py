@@ -232,10 +232,13 @@ class StableDiffusionXLPipeline:
 
     def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):
         """Seeded noise drawn on the HOST (so a seed means the same latent on every device and in
-        the CPU oracle), scaled by the scheduler's initial sigma."""
+        the CPU oracle), scaled by the scheduler's initial sigma.  Drawn IN ``dtype`` like diffusers'
+        ``randn_tensor(shape, generator, device, dtype)`` (reached from
+        /root/reference/latentblending/diffusers_holder.py:98-111 with dtype = float16): on the CPU generator an fp16
+        draw is a different stream from an fp32 draw that is cast afterwards."""
         shape = (batch, channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
         host_gen = torch.Generator().manual_seed(generator.initial_seed())
-        z = torch.randn(shape, generator=host_gen, dtype=torch.float32).to(dtype)
+        z = torch.randn(shape, generator=host_gen, dtype=dtype)
         return (z * self.scheduler.init_noise_sigma).to(self.device)
 
     def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype,

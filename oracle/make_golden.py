@@ -12,6 +12,10 @@ Fixtures
   scheduler.json  closed-form SDXL sigma / timestep known answers
   tree.json       a full run_transition of the reference BlendingEngine on the tiny CPU oracle pipe:
                   census, tree_fracts, tree_idx_injection, similarities, latent / frame checksums
+  configs.json    BASELINE.json configs[2..4] at their STATED tree shape on the tiny CPU oracle pipe, run by the unchanged
+                  reference: cfg 3 (base, 30 steps, depth 0.5, 15 branches, guidance 4.0 -> five injection levels), cfg 4
+                  (turbo, 64 branches, one level), cfg 5 (base, 30 steps, 6 prompts chained with swap_forward +
+                  recycle_img1 as in example_multi_trans.py:39-58)
   frames.json     add_frames_linear_interp of the reference (utils.py:105-178) on seeded uint8 key frames with a seeded
                   numpy RNG: per-gap insert counts and a checksum of every output frame (numpy 2.x arithmetic: the
                   float32 frames are blended in float64)
@@ -219,6 +223,85 @@ def tree_fixture(ref):
     return runs
 
 
+def snapshot(be, imgs, p):
+    """What the tests compare of one finished run_transition."""
+    return {
+        "frames": len(imgs), "unet_calls": p.unet.calls, "vae_calls": p.vae.calls, "noise_draws": p.noise.draws,
+        "list_idx_injection": [int(i) for i in be.list_idx_injection], "list_nmb_stems": [int(s) for s in be.list_nmb_stems],
+        "tree_fracts": [float(f) for f in be.tree_fracts], "tree_idx_injection": [int(i) for i in be.tree_idx_injection],
+        "tree_similarities": [float(s) for s in be.tree_similarities],
+        "final_latent_norm": [float(l[-1].float().norm()) for l in be.tree_latents],
+        "final_latent_head": [[float(v) for v in l[-1].flatten()[:24].float()] for l in be.tree_latents],
+        "frame_mean": [float(np.asarray(i).mean()) for i in imgs],
+        "frame_head": [[int(v) for v in np.asarray(i).flatten()[:24]] for i in imgs],
+        "none_pattern": [[x is None for x in l] for l in be.tree_latents],
+    }
+
+
+CFG5_PROMPTS = ["lake and forest", "alien desolate landscapes", "psychedelic skyscraper city", "a reef at dawn",
+                "fog over a harbour", "desert under two moons"]
+CFG5_SEEDS = [420, 421, 977, 12, 90001, 5]
+CFG5_NEGATIVE = "blurry, pale, low-res, lofi"
+
+
+def configs_fixture(ref):
+    """BASELINE.json configs[2..4] at their stated tree shapes (tiny width), run by the unchanged reference."""
+    out = {}
+    # cfg 3: SDXL base, 30 steps, guidance 4.0, depth 0.5, 15 branches (blending_engine.py:467-529 plans the levels)
+    p = tiny_pipe(turbo=False)
+    np.random.seed(0)
+    with H.cuda_is_identity():
+        be = ref.BlendingEngine(p)
+        be.set_dimensions((128, 128))
+        be.set_num_inference_steps(30)
+        be.set_guidance_scale(4.0)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=15)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        p.noise.reset()
+        p.unet.calls = p.vae.calls = 0
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+    out["cfg3"] = snapshot(be, imgs, p)
+    # cfg 4: SDXL-Turbo, 4 steps, 64 branches on one level
+    p = tiny_pipe(turbo=True)
+    np.random.seed(0)
+    with H.cuda_is_identity():
+        be = ref.BlendingEngine(p)
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=64)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        p.noise.reset()
+        p.unet.calls = p.vae.calls = 0
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+    out["cfg4"] = snapshot(be, imgs, p)
+    # cfg 5: example_multi_trans.py:39-58 with 6 prompts on the base model
+    p = tiny_pipe(turbo=False)
+    np.random.seed(0)
+    segs = []
+    with H.cuda_is_identity():
+        be = ref.BlendingEngine(p)
+        be.set_negative_prompt(CFG5_NEGATIVE)
+        be.set_dimensions((128, 128))
+        be.set_num_inference_steps(30)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=15)
+        p.noise.reset()
+        for i in range(len(CFG5_PROMPTS) - 1):
+            if i == 0:
+                be.set_prompt1(CFG5_PROMPTS[i])
+                be.set_prompt2(CFG5_PROMPTS[i + 1])
+                recycle = False
+            else:
+                be.swap_forward()
+                be.set_prompt2(CFG5_PROMPTS[i + 1])
+                recycle = True
+            p.unet.calls = p.vae.calls = 0
+            imgs = be.run_transition(recycle_img1=recycle, fixed_seeds=CFG5_SEEDS[i:i + 2])
+            segs.append(snapshot(be, imgs, p))
+    out["cfg5"] = {"prompts": CFG5_PROMPTS, "seeds": CFG5_SEEDS, "negative_prompt": CFG5_NEGATIVE, "segments": segs}
+    return out
+
+
 def key_frames(seed, n, h, w):
     rng = np.random.RandomState(seed)
     return [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(n)]
@@ -244,7 +327,7 @@ def main():
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     only = set(sys.argv[1:])
     makers = [("planner", lambda: planner_fixture(ref)), ("slerp", lambda: slerp_fixture(ref)), ("scheduler", scheduler_fixture),
-              ("tree", lambda: tree_fixture(ref)), ("frames", lambda: frames_fixture(ref))]
+              ("tree", lambda: tree_fixture(ref)), ("configs", lambda: configs_fixture(ref)), ("frames", lambda: frames_fixture(ref))]
     for name, make in makers:
         if only and name not in only:
             continue

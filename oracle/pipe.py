@@ -162,7 +162,9 @@ class StableDiffusionXLPipeline:
     def prepare_latents(self, batch, channels, height, width, dtype, device, generator, latents=None):
         shape = (batch, channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
         cpu_gen = torch.Generator().manual_seed(generator.initial_seed())
-        z = torch.randn(shape, generator=cpu_gen, dtype=torch.float32).to(dtype)
+        # diffusers' randn_tensor draws in the requested dtype (fp16 from the reference holder, diffusers_holder.py:98-111):
+        # NOT an fp32 draw cast afterwards - that is a different stream on the CPU generator
+        z = torch.randn(shape, generator=cpu_gen, dtype=dtype)
         return z * self.scheduler.init_noise_sigma
 
     def _get_add_time_ids(self, original_size, crops_coords_top_left, target_size, dtype,

@@ -1,0 +1,61 @@
+"""Shared set-up of BASELINE.json configs[2..4] at their STATED tree shapes on the tiny model width (tests/golden/configs.json
+holds the unchanged reference's runs of exactly these calls: oracle/make_golden.py::configs_fixture)."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gold_configs():
+    with open(os.path.join(ROOT, "tests", "golden", "configs.json")) as fh:
+        return json.load(fh)
+
+
+def setup_cfg3(be):
+    """SDXL base, 30 steps, guidance 4.0, depth 0.5, 15 branches -> levels [15,18,21,24,27] x [4,3,3,2,1]
+    (/root/reference/latentblending/blending_engine.py:467-529)."""
+    be.set_dimensions((128, 128))
+    be.set_num_inference_steps(30)
+    be.set_guidance_scale(4.0)
+    be.set_branching(depth_strength=0.5, nmb_max_branches=15)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+
+
+def setup_cfg4(be):
+    """SDXL-Turbo, 4 steps, 64 branches on one level."""
+    be.set_dimensions((128, 128))
+    be.set_branching(nmb_max_branches=64)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+
+
+def setup_cfg5(be, negative_prompt):
+    """example_multi_trans.py:17-24 before its loop (base model, 30 steps, depth 0.5, 15 branches per transition)."""
+    be.set_negative_prompt(negative_prompt)
+    be.set_dimensions((128, 128))
+    be.set_num_inference_steps(30)
+    be.set_branching(depth_strength=0.5, nmb_max_branches=15)
+
+
+def check_structure(be, imgs, c):
+    """What must be IDENTICAL to the reference run: plan, census of frames, fractions, injection indices, None pattern."""
+    assert len(imgs) == c["frames"]
+    assert [int(i) for i in be.list_idx_injection] == c["list_idx_injection"]
+    assert [int(s) for s in be.list_nmb_stems] == c["list_nmb_stems"]
+    assert [float(f) for f in be.tree_fracts] == c["tree_fracts"], ([float(f) for f in be.tree_fracts], c["tree_fracts"])
+    assert [int(i) for i in be.tree_idx_injection] == c["tree_idx_injection"]
+
+
+def check_values(be, imgs, c, *, sim_rtol, norm_rtol, mean_tol, head_tol):
+    """Numeric agreement with the reference run (CPU fp32 oracle arithmetic): similarities, latent norms, frames."""
+    sims = np.array([float(s) for s in be.tree_similarities])
+    assert np.allclose(sims, c["tree_similarities"], rtol=sim_rtol), (sims.tolist(), c["tree_similarities"])
+    for lat, norm in zip(be.tree_latents, c["final_latent_norm"]):
+        assert abs(float(lat[-1].float().norm()) - norm) <= norm_rtol * norm
+    for img, mean, head in zip(imgs, c["frame_mean"], c["frame_head"]):
+        a = np.asarray(img)
+        assert abs(float(a.mean()) - mean) <= mean_tol, (float(a.mean()), mean)
+        assert np.abs(a.flatten()[:24].astype(int) - np.array(head)).max() <= head_tol

@@ -1,0 +1,93 @@
+"""BASELINE.json configs[2..4] at their STATED tree shapes on a real MI355X (tiny model width): the native engine - HIP
+kernels behind the C-ABI, hipGraph replay, speculative frontier / fused wavefront - against the UNCHANGED reference's
+runs of the same calls on the CPU fp32 oracle pipe, frozen in tests/golden/configs.json (oracle/make_golden.py).
+
+Identical: plan, fractions, injection indices, frame count.  Within the fp16 tolerance of SURVEY.md §8(d): similarities,
+final latents, frames (mean |du8| of a frame's first pixels <= 4, frame means within 1 grey level)."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pipe as OP  # noqa: E402  (checker only: the noise tape and the tiny configs)
+from oracle import sdxl_ref as R  # noqa: E402
+
+from _baseline_cfgs import check_structure, check_values, gold_configs, setup_cfg3, setup_cfg4, setup_cfg5  # noqa: E402
+
+GPU_TOL = dict(sim_rtol=5e-2, norm_rtol=3e-2, mean_tol=1.0, head_tol=4)
+
+
+def native_pipe(turbo):
+    import latentblending_amd.native as n
+    ucfg, vcfg = R.tiny_unet_cfg(), R.tiny_vae_cfg()
+    p = n.NativeSDXLPipe(turbo=turbo, unet_cfg=n.UNetConfig(**dataclasses.asdict(ucfg)),
+                         vae_cfg=n.VAEConfig(**dataclasses.asdict(vcfg)), seed=0)
+    tape = OP.NoiseTape(12345)
+    p.scheduler.noise_source = tape
+    return p, tape
+
+
+@pytest.mark.parametrize("frontier", [1, 16])
+def test_cfg3_stated_tree_native(frontier, results_log):
+    """SDXL base, 30 steps, guidance 4.0 (mid-damped), depth 0.5, 15 branches: five injection levels
+    [15,18,21,24,27] x [4,3,3,2,1] -> multi-level parents (blending_engine.py:550-561 of the reference)."""
+    from latentblending_amd import BlendingEngine
+    c = gold_configs()["cfg3"]
+    p, tape = native_pipe(False)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=frontier)
+    setup_cfg3(be)
+    tape.reset()
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    assert [int(i) for i in be.list_idx_injection] == [15, 18, 21, 24, 27] and [int(s) for s in be.list_nmb_stems] == [4, 3, 3, 2, 1]
+    check_structure(be, imgs, c)
+    check_values(be, imgs, c, **GPU_TOL)
+    results_log[f"cfg3_stated_tree_frontier{frontier}"] = {"frames": len(imgs), "same_tree": True,
+                                                           "sims": [float(s) for s in be.tree_similarities]}
+
+
+@pytest.mark.parametrize("frontier", [1, 64])
+def test_cfg4_stated_tree_native(frontier, results_log):
+    """SDXL-Turbo, 4 steps, 64 branches on one level (66 frames); frontier 64 = the fused wavefront + virtual gaps."""
+    from latentblending_amd import BlendingEngine
+    c = gold_configs()["cfg4"]
+    p, tape = native_pipe(True)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=frontier)
+    setup_cfg4(be)
+    tape.reset()
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    assert len(imgs) == 66
+    check_structure(be, imgs, c)
+    if frontier == 1:       # (a batched frontier consumes the ancestral noise tape in evaluation order, not in commit order)
+        check_values(be, imgs, c, **GPU_TOL)
+    results_log[f"cfg4_stated_tree_frontier{frontier}"] = {"frames": len(imgs), "same_tree": True,
+                                                           "rounds": be.stats.get("frontier_rounds", 0)}
+
+
+@pytest.mark.parametrize("frontier", [1, 16])
+def test_cfg5_six_prompt_chain_native(frontier, results_log):
+    """example_multi_trans.py:39-58 with 6 prompts on the base model through replay.run_multi_transition: five chained
+    transitions, swap_forward + recycle_img1, each with the five-level tree; every segment against the reference's run."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.replay import run_multi_transition
+    g = gold_configs()["cfg5"]
+    p, tape = native_pipe(False)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=frontier)
+    setup_cfg5(be, g["negative_prompt"])
+    tape.reset()
+    seen = []
+
+    def on_segment(i, frames):
+        check_structure(be, frames, g["segments"][i])
+        check_values(be, frames, g["segments"][i], **GPU_TOL)
+        seen.append(len(frames))
+
+    segs = run_multi_transition(be, g["prompts"], g["seeds"], fp_movie=None, on_segment=on_segment)
+    assert seen == [15] * 5 and len(segs) == 5
+    for a, b in zip(segs[:-1], segs[1:]):               # the recycled key frame IS the previous transition's last frame
+        assert np.array_equal(np.asarray(a[-1]), np.asarray(b[0]))
+    results_log[f"cfg5_chain_frontier{frontier}"] = {"segments": len(segs), "frames": seen, "same_trees": True}

@@ -83,6 +83,56 @@ def test_branch_farm_reproduces_sequential_tree(run, world, tmp_path):
         assert r["sims"] == res[0]["sims"] and r["latent_sha"] == res[0]["latent_sha"] and r["frame_sha"] == res[0]["frame_sha"]
 
 
+def _cfg4_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    from _baseline_cfgs import check_structure, gold_configs, setup_cfg4
+    set_backend(R.TorchCpuBackend())
+    c = gold_configs()["cfg4"]
+    p = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+    np.random.seed(0)
+    farm = BranchFarm()
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=64, farm=farm)
+    setup_cfg4(be)
+    p.noise.reset()
+    p.unet.calls = p.vae.calls = 0
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    check_structure(be, imgs, c)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)).tobytes()).hexdigest()[:16]
+    res = {"sims": [float(s) for s in be.tree_similarities], "latent_sha": [sha(l[-1]) for l in be.tree_latents],
+           "frame_sha": [sha(i) for i in imgs], "unet_calls": p.unet.calls, "vae_calls": p.vae.calls,
+           "collectives": farm.collectives, "bytes": farm.bytes_moved, "rounds": be.stats.get("frontier_rounds", 0)}
+    json.dump(res, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_cfg4_shape_at_world_8(tmp_path):
+    """BASELINE.json configs[3]: SDXL-Turbo, 64 branches on one level, sharded over EIGHT ranks (gloo here, RCCL on the
+    node): every rank ends with the 66-frame tree of the sequential reference run (tests/golden/configs.json: identical
+    fractions / injection indices), all ranks bit-identical, and no rank did more than its share of the branch work."""
+    import torch.multiprocessing as mp
+    world = 8
+    port = _free_port()
+    mp.spawn(_cfg4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs.json")))["cfg4"]
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    for r in res:
+        assert len(r["frame_sha"]) == 66 and r["collectives"] > 0 and r["bytes"] > 0
+        # sequential census: 136 UNet calls / 66 decodes; a rank runs the two anchors plus at most its share of the mids
+        assert r["unet_calls"] < gold["unet_calls"] / 2 and r["vae_calls"] < gold["vae_calls"] / 2
+    for r in res[1:]:
+        assert r["sims"] == res[0]["sims"] and r["latent_sha"] == res[0]["latent_sha"] and r["frame_sha"] == res[0]["frame_sha"]
+
+
 def _chain_worker(rank, world, port, out_dir):
     """Two chained transitions (example_multi_trans.py:39-58: swap_forward + recycle_img1) with ancestral noise from a
     tape; world 1 = the farm-less engine in the same frontier mode."""
