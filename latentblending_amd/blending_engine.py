@@ -893,7 +893,44 @@ class BlendingEngine:
             state[name] = value
         state['width'] = self.dh.width_img
         state['height'] = self.dh.height_img
+        # beyond the upstream list: what is needed to restore the engine (upstream never stores its branching plan; its
+        # `depth_strength` key names an attribute that does not exist)
+        state['guidance_scale_base'] = float(self.guidance_scale_base)
+        state['list_idx_injection'] = [int(i) for i in self.list_idx_injection]
+        state['list_nmb_stems'] = [int(s) for s in self.list_nmb_stems]
         return state
+
+    def load_state_dict(self, state):
+        """Inverse of ``get_state_dict`` (the reference has none: its UI re-enters every value by hand,
+        gradio_ui.py:139-149): size, step count, guidance, negative prompt, prompts (re-embedded under that negative
+        prompt and guidance), seeds, crossfeed settings and the branching plan.  A dict read back with ``yml_load``
+        gives the same ``run_transition`` as the engine it was taken from."""
+        if 'width' in state and 'height' in state:
+            self.set_dimensions((int(state['width']), int(state['height'])))
+        if 'num_inference_steps' in state:
+            self.set_num_inference_steps(int(state['num_inference_steps']))
+        for name in ('guidance_scale_mid_damper', 'mid_compression_scaler'):
+            if name in state:
+                setattr(self, name, float(state[name]))
+        if 'guidance_scale_base' in state or 'guidance_scale' in state:
+            self.set_guidance_scale(float(state.get('guidance_scale_base', state.get('guidance_scale'))))
+        if state.get('negative_prompt') is not None:
+            neg = state['negative_prompt']
+            self.set_negative_prompt(neg if isinstance(neg, str) else list(neg))
+        if 'prompt1' in state:
+            self.set_prompt1(state['prompt1'])
+        if 'prompt2' in state:
+            self.set_prompt2(state['prompt2'])
+        if 'guidance_scale' in state:           # (the mid-dampened value the last branch left behind, as upstream stores it)
+            self.guidance_scale = self.dh.guidance_scale = float(state['guidance_scale'])
+        self.seed1, self.seed2 = int(state.get('seed1', self.seed1)), int(state.get('seed2', self.seed2))
+        for name in ('branch1_crossfeed_power', 'branch1_crossfeed_range', 'branch1_crossfeed_decay',
+                     'parental_crossfeed_power', 'parental_crossfeed_range', 'parental_crossfeed_decay'):
+            if name in state:
+                setattr(self, name, float(state[name]))
+        if 'list_idx_injection' in state and 'list_nmb_stems' in state:
+            self.list_idx_injection = [int(i) for i in state['list_idx_injection']]
+            self.list_nmb_stems = [int(s) for s in state['list_nmb_stems']]
 
     def swap_forward(self):
         """Keyframe two becomes keyframe one (multi-transition chains)."""

@@ -1,0 +1,114 @@
+"""Per-user engine state and the multi-user router (minimal form: no widgets).
+
+The reference's gradio front end shares ONE ``BlendingEngine`` per model between all users
+(``latentblending/gradio_ui.py:29-54`` in /root/reference: ``MultiUserRouter.register_new_user`` hands every user a
+``BlendingVariableHolder`` around the same engine object) and the engine keeps its settings in mutable fields of itself,
+of the holder and of the pipe (``dh.guidance_scale``, scheduler tables, negative prompt, image size:
+``diffusers_holder.py:53,224-229``) - so two users' calls overwrite each other's state (SURVEY.md §8b "Threading").
+
+Here the weights, launch programs and hipGraphs stay shared (one engine per model, as upstream), but everything a call
+READS OR LEAVES BEHIND that belongs to a user lives in an :class:`EngineSession`: prompts and their embeddings, negative
+prompt, seeds, size, step count, guidance, crossfeed settings, the branching plan, the transition tree (latents, frames,
+fractions, similarities) and an optional private noise source.  ``with session.bound() as be:`` takes the router's lock,
+installs the session's state on the shared engine, runs the user's calls, and stores what they left behind back into the
+session - calls of different users can interleave in any order and each sees an engine that nobody else touched.
+
+Persistence is the reference's ``get_state_dict`` + ``yml_save`` (``blending_engine.py:709-728``, ``utils.py:245-262``);
+``BlendingEngine.load_state_dict`` is the missing inverse, so ``get_state_dict -> yml_save -> yml_load -> load_state_dict``
+on a fresh engine reproduces the same ``run_transition``.
+"""
+from __future__ import annotations
+
+import contextlib
+import copy
+import threading
+import uuid
+from typing import Dict, Optional
+
+from .tree import TransitionTree
+
+# engine attributes that are per-user state (everything run_transition / compute_latents* read or write)
+_ENGINE_FIELDS = ("prompt1", "prompt2", "text_embedding1", "text_embedding2", "negative_prompt", "seed1", "seed2",
+                  "guidance_scale_base", "guidance_scale", "guidance_scale_mid_damper", "mid_compression_scaler",
+                  "branch1_crossfeed_power", "branch1_crossfeed_range", "branch1_crossfeed_decay",
+                  "parental_crossfeed_power", "parental_crossfeed_range", "parental_crossfeed_decay",
+                  "num_inference_steps", "list_idx_injection", "list_nmb_stems", "image1_lowres", "image2_lowres",
+                  "multi_transition_img_first", "multi_transition_img_last", "_preset_anchor_frames", "stats")
+# holder attributes that follow them
+_HOLDER_FIELDS = ("negative_prompt", "guidance_scale", "num_inference_steps", "width_img", "height_img", "width_latent",
+                  "height_latent")
+
+
+class EngineSession:
+    """One user's view of a shared ``BlendingEngine``."""
+
+    def __init__(self, be, lock: Optional[threading.RLock] = None, noise_source=None):
+        self.be = be
+        self._lock = lock if lock is not None else threading.RLock()
+        self.noise_source = noise_source            # optional private ancestral-noise source (native pipes)
+        self._engine = {k: copy.copy(getattr(be, k)) for k in _ENGINE_FIELDS}
+        self._engine["stats"] = {}
+        self._holder = {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}
+        self._tree = TransitionTree()               # a user never sees another user's tree
+
+    @contextlib.contextmanager
+    def bound(self):
+        """Install this session on the shared engine for the duration of the block (exclusive)."""
+        be = self.be
+        with self._lock:
+            for k, v in self._engine.items():
+                setattr(be, k, v)
+            for k, v in self._holder.items():
+                setattr(be.dh, k, v)
+            be._tree = self._tree
+            be.dh.set_num_inference_steps(self._holder["num_inference_steps"])     # scheduler tables are pipe state
+            sched = getattr(be.dh.pipe, "scheduler", None)
+            swap_noise = self.noise_source is not None and hasattr(sched, "noise_source")
+            if swap_noise:
+                previous, sched.noise_source = sched.noise_source, self.noise_source
+            try:
+                yield be
+            finally:
+                if swap_noise:
+                    sched.noise_source = previous
+                self._engine = {k: getattr(be, k) for k in _ENGINE_FIELDS}
+                self._holder = {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}
+                self._tree = be._tree
+
+    # conveniences mirroring what the UI holder calls (gradio_ui.py:139-149, 238-256)
+    def run_transition(self, **kw):
+        with self.bound() as be:
+            return be.run_transition(**kw)
+
+    def get_state_dict(self) -> Dict:
+        with self.bound() as be:
+            return be.get_state_dict()
+
+    def load_state_dict(self, state: Dict):
+        with self.bound() as be:
+            be.load_state_dict(state)
+
+
+class SessionRouter:
+    """``MultiUserRouter`` without the widgets (gradio_ui.py:29-54): engines per model name, sessions per user id, one
+    lock per engine so that users of different models do not wait for each other."""
+
+    def __init__(self, engines: Dict[str, object]):
+        self.dict_blendingengines = dict(engines)
+        self._locks = {m: threading.RLock() for m in self.dict_blendingengines}
+        self.user_sessions: Dict[str, EngineSession] = {}
+
+    def register_new_user(self, model: str, width: int, height: int, noise_source=None) -> str:
+        user_id = str(uuid.uuid4().hex.upper()[0:8])
+        be = self.dict_blendingengines[model]
+        session = EngineSession(be, self._locks[model], noise_source=noise_source)
+        with session.bound() as engine:
+            engine.set_dimensions((width, height))
+        self.user_sessions[user_id] = session
+        return user_id
+
+    def session(self, user_id: str) -> EngineSession:
+        return self.user_sessions[user_id]
+
+    def drop_user(self, user_id: str) -> None:
+        self.user_sessions.pop(user_id, None)

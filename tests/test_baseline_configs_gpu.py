@@ -91,3 +91,40 @@ def test_cfg5_six_prompt_chain_native(frontier, results_log):
     for a, b in zip(segs[:-1], segs[1:]):               # the recycled key frame IS the previous transition's last frame
         assert np.array_equal(np.asarray(a[-1]), np.asarray(b[0]))
     results_log[f"cfg5_chain_frontier{frontier}"] = {"segments": len(segs), "frames": seen, "same_trees": True}
+
+
+def test_state_round_trip_and_sessions_native(tmp_path, results_log):
+    """SURVEY.md §8f rank 4 on the native path: get_state_dict -> yml_save -> yml_load -> load_state_dict on a second engine
+    over the same pipe reproduces run_transition bit for bit; two sessions sharing that engine do not see each other's state."""
+    from latentblending_amd import BlendingEngine, SessionRouter, yml_load, yml_save
+    p, tape = native_pipe(True)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=8)
+    be.set_dimensions((128, 128))
+    be.set_parental_crossfeed(0.8, 0.5, 0.5)
+    be.set_branching(nmb_max_branches=6)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+    be.seed1, be.seed2 = 420, 421
+    fp = str(tmp_path / "state.yml")
+    yml_save(fp, be.get_state_dict())
+    tape.reset()
+    want = [np.asarray(i).copy() for i in be.run_transition()]
+    be2 = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=8)
+    be2.load_state_dict(yml_load(fp))
+    tape.reset()
+    got = [np.asarray(i).copy() for i in be2.run_transition()]
+    assert be2.tree_fracts == be.tree_fracts and all(np.array_equal(a, b) for a, b in zip(got, want))
+    router = SessionRouter({"turbo": be})
+    ua, ub = router.register_new_user("turbo", 128, 128), router.register_new_user("turbo", 128, 128)
+    with router.session(ub).bound() as e:
+        e.set_branching(nmb_max_branches=3)
+        e.set_prompt1("fog"); e.set_prompt2("a harbour")
+        tape.reset()
+        other = e.run_transition(fixed_seeds=[1, 2])
+    with router.session(ua).bound() as e:       # user A still has the engine's original settings and gets the original frames
+        assert e.prompt1 == "photo of a reef" and int(e.list_nmb_stems[0]) == 6
+        tape.reset()
+        again = [np.asarray(i).copy() for i in e.run_transition()]
+    assert len(other) == 5 and all(np.array_equal(a, b) for a, b in zip(again, want))
+    results_log["state_round_trip_native"] = {"frames": len(got), "bit_identical": True}

@@ -236,6 +236,23 @@ def test_live_differential_against_unchanged_reference(cpu_backend):
         assert len(x) == len(y) and all(np.array_equal(a, b) for a, b in zip(x, y))
 
 
+@pytest.mark.parametrize("turbo,seed", [(True, 420), (True, 421), (False, 7)])
+def test_get_noise_is_diffusers_prepare_latents(turbo, seed, cpu_backend):
+    """``DiffusersHolder.get_noise`` -> ``pipe.prepare_latents(1, 4, H, W, torch.float16, device, Generator.manual_seed(seed))``
+    (/root/reference/latentblending/diffusers_holder.py:98-111); diffusers' randn_tensor draws IN the requested dtype
+     - on the CPU generator an fp16 draw is a different stream from an fp32 draw cast to fp16
+    (seed 420: first value 0.9907 vs -0.0070), which is what rounds 1-3 shipped."""
+    from latentblending_amd import DiffusersHolder
+    p = tiny_pipe(turbo)
+    dh = DiffusersHolder(p)
+    dh.set_dimensions((128, 128))
+    z = dh.get_noise(seed)
+    want = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(seed), dtype=torch.float16) * p.scheduler.init_noise_sigma
+    assert z.dtype == torch.float16 and z.shape == (1, 4, 16, 16) and torch.equal(z, want)
+    wrong = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(seed), dtype=torch.float32).to(torch.float16)
+    assert not torch.equal(z, wrong * p.scheduler.init_noise_sigma)
+
+
 def test_reference_error_behaviour_is_kept(cpu_backend):
     from latentblending_amd import BlendingEngine
     p = tiny_pipe(True)

@@ -132,6 +132,10 @@ def test_native_pipe_duck_type_under_generic_loop(results_log):
     assert torch.equal(emb_o[0], emb_p[0].cpu())
     z_o, z_p = dh_o.get_noise(420), dh_p.get_noise(420)
     assert torch.equal(z_o, z_p.cpu())
+    # ... and that latent IS diffusers' prepare_latents of the reference's get_noise (diffusers_holder.py:98-111):
+    # randn drawn IN fp16 from the seeded generator (not an fp32 draw cast afterwards), times init_noise_sigma
+    want = torch.randn((1, 4, 16, 16), generator=torch.Generator().manual_seed(420), dtype=torch.float16) * p.scheduler.init_noise_sigma
+    assert z_p.dtype == torch.float16 and torch.equal(z_p.cpu(), want)
     set_backend(R.TorchCpuBackend())
     o.noise.reset()
     ref = dh_o._denoise_generic(emb_o, z_o, 0, None, [0.0] * 4)

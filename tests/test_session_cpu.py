@@ -1,0 +1,158 @@
+"""SURVEY.md §8f rank 4 (minimal form): the persisted engine state round-trips through the reference's yml files, and
+several users share ONE engine (weights, programs) through per-user sessions without seeing each other's state
+(/root/reference/latentblending/blending_engine.py:709-728, gradio_ui.py:29-54)."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import pipe as OP
+from oracle import sdxl_ref as R
+
+
+@pytest.fixture()
+def cpu_backend():
+    from latentblending_amd.backend import set_backend
+    set_backend(R.TorchCpuBackend())
+    yield
+    set_backend(None)
+
+
+def tiny_pipe(turbo):
+    return OP.StableDiffusionXLPipeline(turbo=turbo, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+
+
+def frames_of(imgs):
+    return [np.asarray(i).copy() for i in imgs]
+
+
+def test_state_dict_round_trips_through_yml(tmp_path, cpu_backend):
+    from latentblending_amd import BlendingEngine, yml_load, yml_save
+    p = tiny_pipe(False)
+    np.random.seed(0)
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+    be.set_dimensions((64, 64))
+    be.set_num_inference_steps(6)
+    be.set_guidance_scale(3.0)
+    be.set_negative_prompt("blurry, pale")
+    be.set_branch1_crossfeed(0.3, 0.5, 0.5)
+    be.set_branching(depth_strength=0.5, nmb_max_branches=5)
+    be.set_prompt1("photo of a reef")
+    be.set_prompt2("rendering of an alien planet")
+    be.seed1, be.seed2 = 420, 421
+    state = be.get_state_dict()
+    for key in ("prompt1", "prompt2", "seed1", "seed2", "width", "height", "num_inference_steps", "guidance_scale",
+                "guidance_scale_mid_damper", "negative_prompt", "branch1_crossfeed_power", "parental_crossfeed_decay"):
+        assert key in state                    # (the reference's key list, blending_engine.py:711-715, with its typos fixed)
+    fp = str(tmp_path / "state.yml")
+    yml_save(fp, state)
+    want = frames_of(be.run_transition())
+    tree = (list(be.tree_fracts), list(be.tree_idx_injection))
+
+    p2 = tiny_pipe(False)
+    be2 = BlendingEngine(p2, metric=R.OracleLPIPS(7), verbose=False)
+    be2.load_state_dict(yml_load(fp))
+    assert be2.get_state_dict() == state
+    got = frames_of(be2.run_transition())
+    assert (list(be2.tree_fracts), list(be2.tree_idx_injection)) == tree
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_sessions_isolate_users_of_one_engine(cpu_backend):
+    """Two users with different settings interleave calls on ONE shared engine; each gets exactly what a dedicated engine
+    gives, including a chained second transition that recycles the user's OWN previous tree."""
+    from latentblending_amd import BlendingEngine, SessionRouter
+
+    def user_a(be):
+        be.set_num_inference_steps(6)
+        be.set_guidance_scale(3.0)              # (> 1: this user runs classifier-free guidance with a negative prompt)
+        be.set_negative_prompt("blurry")
+        be.set_parental_crossfeed(0.8, 0.5, 0.5)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=4)
+        be.set_prompt1("a reef"); be.set_prompt2("an alien planet")
+
+    def user_b(be):
+        be.set_num_inference_steps(4)
+        be.set_branching(depth_strength=0.25, nmb_max_branches=3)
+        be.set_prompt1("fog"); be.set_prompt2("a harbour")
+
+    def run(be, pipe, **kw):                    # (ancestral sampler: every transition starts the noise tape afresh)
+        pipe.noise.reset()
+        return frames_of(be.run_transition(**kw))
+
+    def dedicated(setup, second_prompt):
+        np.random.seed(0)
+        p = tiny_pipe(True)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False)
+        be.set_dimensions((64, 64))
+        setup(be)
+        first = run(be, p, fixed_seeds=[5, 6])
+        be.swap_forward(); be.set_prompt2(second_prompt)
+        second = run(be, p, recycle_img1=True, fixed_seeds=[6, 7])
+        return first, second, list(be.tree_fracts)
+
+    want_a, want_b = dedicated(user_a, "a forest"), dedicated(user_b, "a desert")
+
+    np.random.seed(0)
+    ps = tiny_pipe(True)
+    shared = BlendingEngine(ps, metric=R.OracleLPIPS(7), verbose=False)
+    router = SessionRouter({"turbo": shared})
+    ua, ub = router.register_new_user("turbo", 64, 64), router.register_new_user("turbo", 64, 64)
+    sa, sb = router.session(ua), router.session(ub)
+    with sa.bound() as be:
+        user_a(be)
+    with sb.bound() as be:
+        user_b(be)
+    with sa.bound() as be:
+        a1 = run(be, ps, fixed_seeds=[5, 6])
+    with sb.bound() as be:                                                 # B runs between A's two transitions
+        b1 = run(be, ps, fixed_seeds=[5, 6])
+    with sa.bound() as be:
+        assert be.num_inference_steps == 6 and be.dh.num_inference_steps == 6 and be.guidance_scale_base == 3.0
+        be.swap_forward(); be.set_prompt2("a forest")
+        a2 = run(be, ps, recycle_img1=True, fixed_seeds=[6, 7])
+        fr_a = list(be.tree_fracts)
+    with sb.bound() as be:
+        assert be.num_inference_steps == 4 and be.negative_prompt is None and be.guidance_scale_base == 0.0
+        be.swap_forward(); be.set_prompt2("a desert")
+        b2 = run(be, ps, recycle_img1=True, fixed_seeds=[6, 7])
+        fr_b = list(be.tree_fracts)
+    for got, want in (((a1, a2, fr_a), want_a), ((b1, b2, fr_b), want_b)):
+        assert got[2] == want[2]
+        for x, y in zip(got[0] + got[1], want[0] + want[1]):
+            assert np.array_equal(x, y)
+    assert sa.get_state_dict()["prompt2"] == "a forest" and sb.get_state_dict()["prompt2"] == "a desert"
+
+
+def test_sessions_serialise_concurrent_callers(cpu_backend):
+    """Two threads drive two users of one engine at once: calls serialise on the engine's lock, results are per user."""
+    from latentblending_amd import BlendingEngine, SessionRouter
+    np.random.seed(0)
+    shared = BlendingEngine(tiny_pipe(True), metric=R.OracleLPIPS(7), verbose=False)
+    router = SessionRouter({"turbo": shared})
+    users = [router.register_new_user("turbo", 64, 64) for _ in range(2)]
+    out, errors = {}, []
+
+    def work(uid, steps, seeds):
+        try:
+            from latentblending_amd.backend import set_backend
+            set_backend(R.TorchCpuBackend())
+            s = router.session(uid)
+            with s.bound() as be:
+                be.set_num_inference_steps(steps)
+                be.set_branching(depth_strength=0.5, nmb_max_branches=3)
+                be.set_prompt1("a"); be.set_prompt2("b")
+            out[uid] = (frames_of(s.run_transition(fixed_seeds=seeds)), steps)
+        except Exception as exc:       # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(users[0], 4, [1, 2])), threading.Thread(target=work, args=(users[1], 6, [3, 4]))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for uid in users:
+        frames, steps = out[uid]
+        with router.session(uid).bound() as be:
+            assert be.num_inference_steps == steps and len(be.tree_latents[0]) == steps and len(frames) == len(be.tree_fracts)
