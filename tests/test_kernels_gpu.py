@@ -780,3 +780,56 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
     ref = F.silu(F.group_norm(y.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)).permute(0, 2, 3, 1)
     check_close(results_log, f"groupnorm_from_conv_stats_{'_'.join(map(str, case))}", got, ref)
     assert (got.float() - two_pass.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+# ------------------------------------------------------------------ ping-pong 256x256 GEMM (gemm_pp.hip, tile code 9)
+PP_SHAPES = [(4352, 1280, 1280), (512, 768, 640), (300, 260, 128), (1000, 3840, 64), (256, 256, 192), (4352, 512, 5120)]
+
+
+@pytest.mark.parametrize("prio", [1, 0])
+@pytest.mark.parametrize("shape", PP_SHAPES)
+def test_gemm_pingpong(shape, prio, results_log):
+    """gemm_pp.hip against the fp32 reference AND bit for bit against the lock-step tiles (same K order per accumulator);
+    ragged M / N (masked rows read the zero page), K = 64 (one K-tile: prologue + drain only), an odd number of K-tiles,
+    bias / residual epilogue.  Repeated launches: a staging race would show as run-to-run differences."""
+    o, l = ops(), lib()
+    M, N, K = shape
+    A, W = rnd(M, K, seed=91), rnd(N, K, seed=92, scale=K ** -0.5)
+    bias, res = rnd(N, seed=93, dtype=torch.float32), rnd(M, N, seed=94)
+    ref = A.float() @ W.float().t() + bias + res.float()
+    Ad, Wd, bd, rd = A.to(DEV), W.to(DEV), bias.to(DEV), res.to(DEV)
+    l.api.lb_gemm_set_tuning(1, 1)
+    try:
+        lock_step = o.gemm(Ad, Wd, bias=bd, residual=rd)
+        l.api.lb_gemm_set_tuning(9, 1)
+        l.api.lb_gemm_pp_set_prio(prio)
+        runs = [o.gemm(Ad, Wd, bias=bd, residual=rd) for _ in range(6)]
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+        l.api.lb_gemm_pp_set_prio(1)
+    check_close(results_log, f"pp_gemm_{M}x{N}x{K}_prio{prio}", runs[0], ref)
+    assert torch.equal(runs[0], lock_step)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+
+
+def test_gemm_pingpong_geglu_and_splitk(results_log):
+    o, l = ops(), lib()
+    l.api.lb_gemm_set_tuning(9, 1)
+    try:
+        for (M, C, mult) in [(4352, 1280, 8), (300, 640, 8), (520, 320, 2)]:
+            A, W = rnd(M, C, seed=95), rnd(mult * C, C, seed=96, scale=C ** -0.5)
+            bias = rnd(mult * C, seed=97, dtype=torch.float32, scale=0.1)
+            h, gate = (A.float() @ W.float().t() + bias).chunk(2, dim=-1)
+            got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_GEGLU)
+            assert got.shape == (M, mult * C // 2)
+            check_close(results_log, f"pp_geglu_{M}x{C}x{mult}", got, h * F.gelu(gate))
+            l.api.lb_gemm_set_tuning(1, 1)
+            assert torch.equal(o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_GEGLU), got)
+            l.api.lb_gemm_set_tuning(9, 1)
+        l.api.lb_gemm_set_tuning(9, 3)                       # split-K slabs through the ping-pong loop (uneven slices: 20 K-tiles / 3)
+        A, W = rnd(512, 1280, seed=98), rnd(768, 1280, seed=99, scale=1280 ** -0.5)
+        got = o.gemm(A.to(DEV), W.to(DEV))
+        check_close(results_log, "pp_splitk3", got, A.float() @ W.float().t())
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
