@@ -47,7 +47,17 @@ template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
 // PRIO: s_setprio 1 around the MFMA clusters (the partner wave's load segment then never delays an MFMA issue)
-template <bool GEGLU, bool PRIO>
+// MODE 0: TWO barriers per phase - load segment | barrier | compute segment | barrier, the second group one barrier late.
+// MODE 1: ONE barrier per phase.  Between two barriers the early group (wr = 0) runs [compute phase k, load phase k + 1]
+//         while the late group (wr = 1) runs [load phase k, compute phase k]: the roles still alternate inside the interval
+//         (matrix beside memory, then memory beside matrix), but the hand-over in the middle is not a rendezvous - the late
+//         group's MFMAs simply follow the early group's through the SIMD's matrix pipe - and only half as many
+//         workgroup-wide synchronisations are paid per K-tile.  The early group reads a half-tile one interval BEFORE the
+//         late group does, so (RAW) the late group waits for its part of a half-tile one phase earlier (vmcnt(6) instead of
+//         vmcnt(8): three half-tiles instead of four may still be in flight at its wait); WAR is unchanged (a slot is
+//         requested again by load segment p, its last read belongs to phase <= p - 2, i.e. to an EARLIER interval for
+//         both groups, and the reads issued at the end of an interval are waited for by their own wave before it computes).
+template <bool GEGLU, bool PRIO, int MODE>
 __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) {
     constexpr int BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
@@ -83,21 +93,22 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     const int nkt = kt_end - kt_begin;
 
     // ---- staging: a half-tile = 128 LDS rows of 128 B = two wave instructions per wave (rows n*64 + wave*8 + lr) ----
-    // lane (lr = lane >> 3, s = lane & 7) owns physical chunk s of its row and fetches logical chunk s ^ (row & 7)
+    // lane (lr = lane >> 3, s = lane & 7) owns physical chunk s of its row and fetches logical chunk s ^ (row & 7).
+    // Per-lane state is ONE 32-bit byte offset per staged row (8 VGPRs); the K position is a scalar added to the uniform
+    // base, so the requests take the `saddr + voffset` form and nothing per-lane changes inside the K loop.  No masking:
+    // rows beyond M / N re-read the last valid row (their accumulator rows / columns are never stored), requests beyond
+    // the K range re-read the last K-tile (staged into slots nobody reads again).
     const int lr = lane >> 3;
     const int cl = (lane & 7) ^ (lr & 7);
-    const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
-    const lb_half* a_src[4];         // [qm * 2 + n]: LDS row n*64 + wave*8 + lr of half-tile A_qm = block row n*128 + qm*64 + wave*8 + lr
-    const lb_half* w_src[4];         // [qn * 2 + n]
-    int a_step[4], w_step[4];        // halves per K-tile (0 for masked rows: they keep reading the zero page)
+    unsigned a_off[4];               // [qm * 2 + n]: LDS row n*64 + wave*8 + lr of half-tile A_qm = block row n*128 + qm*64 + wave*8 + lr
+    unsigned w_off[4];               // [qn * 2 + n]
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const int m = m0 + n * 128 + qm * 64 + wave * 8 + lr;
-            const bool ok = m < p.M;
-            a_src[qm * 2 + n] = ok ? p.A + (long)m * p.lda + (long)kt_begin * PP_BK + cl * 8 : zero;
-            a_step[qm * 2 + n] = ok ? PP_BK : 0;
+            int m = m0 + n * 128 + qm * 64 + wave * 8 + lr;
+            m = m < p.M ? m : p.M - 1;
+            a_off[qm * 2 + n] = (unsigned)(((long)m * p.lda + cl * 8) * 2);
         }
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
@@ -106,33 +117,32 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
             // LDS row r = n*64 + wave*8 + lr of half-tile B_qn belongs to wave column r >> 5, fragment (r >> 4) & 1, row r & 15
             const int wcc = 2 * n + (wave >> 2);
             long wrow;
-            bool ok;
             if (GEGLU) {             // fragment 0 = h, 1 = gate of output columns n0 + (wcc*2 + qn)*16 + 0..15
-                const int oc = n0 + (wcc * 2 + qn) * 16 + (wave & 1) * 8 + lr;
-                ok = oc < n_eff;
+                int oc = n0 + (wcc * 2 + qn) * 16 + (wave & 1) * 8 + lr;
+                oc = oc < n_eff ? oc : n_eff - 1;
                 wrow = (long)((wave >> 1) & 1) * n_eff + oc;
             } else {
                 const int col = n0 + wcc * 64 + qn * 32 + (wave & 3) * 8 + lr;
-                ok = col < p.N;
-                wrow = col;
+                wrow = col < p.N ? col : p.N - 1;
             }
-            w_src[qn * 2 + n] = ok ? p.W + wrow * p.ldw + (long)kt_begin * PP_BK + cl * 8 : zero;
-            w_step[qn * 2 + n] = ok ? PP_BK : 0;
+            w_off[qn * 2 + n] = (unsigned)((wrow * p.ldw + cl * 8) * 2);
         }
+    const char* const a_base = reinterpret_cast<const char*>(p.A) + (long)kt_begin * (PP_BK * 2);
+    const char* const w_base = reinterpret_cast<const char*>(p.W) + (long)kt_begin * (PP_BK * 2);
 
-    // request half-tile J (0 = A0, 1 = B0, 2 = B1, 3 = A1) of the next K-tile of that kind into ring slot 4*d + J
-    auto stage = [&](auto jc, int d, bool live) {
+    // request half-tile J (0 = A0, 1 = B0, 2 = B1, 3 = A1) of K-tile `tile` (of this block's range) into ring slot 4*(tile & 1) + J
+    auto stage = [&](auto jc, int tile) {
         constexpr int J = decltype(jc)::value;
         constexpr bool IS_A = (J == 0 || J == 3);
         constexpr int Q = (J == 0 || J == 1) ? 0 : 1;                 // qm for A, qn for B
+        const int d = tile & 1;
+        const int kt = tile < nkt ? tile : nkt - 1;
+        const long koff = (long)kt * (PP_BK * 2);                     // scalar
         f16* base = lds + (4 * d + J) * PP_SLOT_H + (wave * 8) * PP_BK;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-            const lb_half*& ptr = IS_A ? a_src[Q * 2 + n] : w_src[Q * 2 + n];
-            const int step = IS_A ? a_step[Q * 2 + n] : w_step[Q * 2 + n];
-            const lb_half* src = live ? ptr : zero;
+            const char* src = (IS_A ? a_base : w_base) + koff + (size_t)(IS_A ? a_off[Q * 2 + n] : w_off[Q * 2 + n]);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + n * 64 * PP_BK), 16, 0, 0);
-            ptr += step;
         }
     };
 
@@ -185,59 +195,111 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     };
 
     // ---- prologue: half-tiles 0..5 (K-tile 0 whole, A0 / B0 of K-tile 1) ----
-    stage(J0{}, 0, true);
-    stage(J1{}, 0, true);
-    stage(J2{}, 0, true);
-    stage(J3{}, 0, true);
-    stage(J0{}, 1, 1 < nkt);
-    stage(J1{}, 1, 1 < nkt);
+    stage(J0{}, 0);
+    stage(J1{}, 0);
+    stage(J2{}, 0);
+    stage(J3{}, 0);
+    stage(J0{}, 1);
+    stage(J1{}, 1);
     pp_wait_vm<8>();                         // A0 / B0 of K-tile 0 have landed (this wave's part)
     pp_barrier();
-    if (wr == 1) pp_barrier();               // the second group runs one barrier interval behind the first
-    __builtin_amdgcn_sched_barrier(0);
 
-    for (int t = 0; t < nkt; ++t) {
+    // load segments of the four phases of K-tile t (d = t & 1; VM = the vmcnt this group waits for, -1 = none)
+    auto load0 = [&](int t, auto vm) {       // reads A0, B0; requests B1 of K-tile t + 1
         const int d = t & 1;
-        const int doff = d * 4 * PP_SLOT_H;
-        const bool live1 = t + 1 < nkt, live2 = t + 2 < nkt;
-        // phase 0: A0 x B0
-        read_b(J1{}, doff, b0);
-        read_a(J0{}, doff);
-        stage(J2{}, d ^ 1, live1);
-        pp_wait_vm<8>();                     // B1 of this K-tile landed
+        read_b(J1{}, d * 4 * PP_SLOT_H, b0);
+        read_a(J0{}, d * 4 * PP_SLOT_H);
+        stage(J2{}, t + 1);
+        if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
+    };
+    auto load1 = [&](int t, auto vm) {       // reads B1; requests A1 of K-tile t + 1
+        const int d = t & 1;
+        read_b(J2{}, d * 4 * PP_SLOT_H, b1);
+        stage(J3{}, t + 1);
+        if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
+    };
+    auto load2 = [&](int t, auto vm) {       // reads A1; requests A0 of K-tile t + 2
+        const int d = t & 1;
+        read_a(J3{}, d * 4 * PP_SLOT_H);
+        stage(J0{}, t + 2);
+        if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
+    };
+    auto load3 = [&](int t, auto vm) {       // reads nothing (B0 stayed in registers); requests B0 of K-tile t + 2
+        const int d = t & 1;
+        stage(J1{}, t + 2);
+        if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
+    };
+    auto compute = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2]) {
+        __builtin_amdgcn_sched_barrier(0);
+        mma(qmc, qnc, bf);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef PPInt<-1> NOWAIT;
+    typedef PPInt<8> VM8;
+    typedef PPInt<6> VM6;
+
+    if constexpr (MODE == 0) {
+        if (wr == 1) pp_barrier();           // the second group runs one barrier interval behind the first
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < nkt; ++t) {
+            load0(t, VM8{});                 // ... B1 of this K-tile landed
+            pp_barrier();
+            compute(J0{}, J0{}, b0);
+            pp_barrier();
+            load1(t, VM8{});                 // ... A1 of this K-tile landed
+            pp_barrier();
+            compute(J0{}, J1{}, b1);
+            pp_barrier();
+            load2(t, NOWAIT{});
+            pp_barrier();
+            compute(J1{}, J1{}, b1);
+            pp_barrier();
+            load3(t, VM8{});                 // ... A0 / B0 of the next K-tile landed
+            pp_barrier();
+            compute(J1{}, J0{}, b0);
+            pp_barrier();
+        }
+        if (wr == 0) pp_barrier();           // pairs with the late group's last barrier
+    } else if (wr == 0) {
+        // early group: [compute phase k | load phase k + 1] per interval
+        load0(0, VM8{});
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mma(J0{}, J0{}, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        // phase 1: A0 x B1
-        read_b(J2{}, doff, b1);
-        stage(J3{}, d ^ 1, live1);
-        pp_wait_vm<8>();                     // A1 of this K-tile landed
-        pp_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        mma(J0{}, J1{}, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        // phase 2: A1 x B1
-        read_a(J3{}, doff);
-        stage(J0{}, d, live2);
-        pp_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        mma(J1{}, J1{}, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
-        // phase 3: A1 x B0 (no reads)
-        stage(J1{}, d, live2);
-        pp_wait_vm<8>();                     // A0 / B0 of the next K-tile landed
+        for (int t = 0; t < nkt; ++t) {
+            compute(J0{}, J0{}, b0);
+            load1(t, VM8{});
+            pp_barrier();
+            compute(J0{}, J1{}, b1);
+            load2(t, NOWAIT{});
+            pp_barrier();
+            compute(J1{}, J1{}, b1);
+            load3(t, VM8{});
+            pp_barrier();
+            compute(J1{}, J0{}, b0);
+            load0(t + 1, VM8{});             // (past the last K-tile: reads of stale slots into dead registers)
+            pp_barrier();
+        }
+    } else {
+        // late group: [load phase k | compute phase k] per interval; its waits cover what the EARLY group reads in the next interval
+        pp_wait_vm<6>();                     // B1 of K-tile 0 (the early group reads it in interval 0)
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mma(J1{}, J0{}, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        pp_barrier();
+        for (int t = 0; t < nkt; ++t) {
+            load0(t, VM6{});                 // ... A1 of this K-tile landed
+            compute(J0{}, J0{}, b0);
+            pp_barrier();
+            load1(t, NOWAIT{});
+            compute(J0{}, J1{}, b1);
+            pp_barrier();
+            load2(t, VM6{});                 // ... A0 / B0 of the next K-tile landed
+            compute(J1{}, J1{}, b1);
+            pp_barrier();
+            load3(t, VM6{});                 // ... B1 of the next K-tile landed
+            compute(J1{}, J0{}, b0);
+            pp_barrier();
+        }
     }
-    if (wr == 0) pp_barrier();               // pairs with the late group's last barrier
-    pp_wait_vm<0>();                         // masked tail requests (zero page) drained before the epilogue / exit
+    pp_wait_vm<0>();                         // the tail requests (re-reads of the last K-tile) drained before the epilogue / exit
 
     // ---- epilogue (shared with the other GEMM kernels) ----
     if (p.splitk > 1) {
@@ -257,27 +319,34 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     lb_gemm_tile_epilogue<8, 4, GEGLU>(p, acc, m0 + wr * 128 + l16, n0 + wc * 64 + 4 * g, n0 + wc * 32 + 4 * g);
 }
 
-static int g_pp_prio = 1;
-extern "C" void lb_gemm_pp_set_prio(int on) { g_pp_prio = on; }
+static int g_pp_prio = 1, g_pp_mode = 1;
+extern "C" void lb_gemm_pp_set_tuning(int prio, int mode) { g_pp_prio = prio; g_pp_mode = mode; }
 
 int lb_gemm_pp_eligible(const LbGemmParams& p) {
-    return !p.conv && p.zero_page != nullptr && p.K % PP_BK == 0 && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_CH_STATS)) &&
-           p.lda % 8 == 0 && p.ldw % 8 == 0;
+    return !p.conv && p.K % PP_BK == 0 && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_CH_STATS)) && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
+           (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);       // 32-bit row offsets
+}
+
+template <bool GEGLU, bool PRIO, int MODE>
+static void pp_launch(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+    static unsigned long long seen = 0;
+    if (lb_first_call_on_device(seen))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU, PRIO, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU, PRIO, MODE>), grid, dim3(512), PP_LDS_BYTES, stream, p);
 }
 
 int lb_gemm_launch_pp(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
-    static unsigned long long seen = 0;
-    if (lb_first_call_on_device(seen)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-    }
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
-    const dim3 block(512);
-    if (geglu && g_pp_prio) hipLaunchKernelGGL((gemm_f16_pp_kernel<true, true>), grid, block, PP_LDS_BYTES, stream, p);
-    else if (geglu) hipLaunchKernelGGL((gemm_f16_pp_kernel<true, false>), grid, block, PP_LDS_BYTES, stream, p);
-    else if (g_pp_prio) hipLaunchKernelGGL((gemm_f16_pp_kernel<false, true>), grid, block, PP_LDS_BYTES, stream, p);
-    else hipLaunchKernelGGL((gemm_f16_pp_kernel<false, false>), grid, block, PP_LDS_BYTES, stream, p);
+    const int key = (geglu ? 4 : 0) | (g_pp_prio ? 2 : 0) | (g_pp_mode ? 1 : 0);
+    switch (key) {
+        case 0: pp_launch<false, false, 0>(p, grid, stream); break;
+        case 1: pp_launch<false, false, 1>(p, grid, stream); break;
+        case 2: pp_launch<false, true, 0>(p, grid, stream); break;
+        case 3: pp_launch<false, true, 1>(p, grid, stream); break;
+        case 4: pp_launch<true, false, 0>(p, grid, stream); break;
+        case 5: pp_launch<true, false, 1>(p, grid, stream); break;
+        case 6: pp_launch<true, true, 0>(p, grid, stream); break;
+        default: pp_launch<true, true, 1>(p, grid, stream); break;
+    }
     return 0;
 }

@@ -59,3 +59,22 @@ def check_values(be, imgs, c, *, sim_rtol, norm_rtol, mean_tol, head_tol):
         a = np.asarray(img)
         assert abs(float(a.mean()) - mean) <= mean_tol, (float(a.mean()), mean)
         assert np.abs(a.flatten()[:24].astype(int) - np.array(head)).max() <= head_tol
+
+
+def check_structure_cfg4_batched(be, imgs, c):
+    """cfg 4 evaluated as ONE speculative batch: the ancestral sampler's noise tape is then consumed in evaluation order
+    instead of the sequential engine's commit order, so every mid branch is a different (equally valid) sample and the
+    near-tied choice of the LAST gap may differ from the sequential run.  What is structural stays: 63 of the 64 mid
+    branches fill the 1/64 grid completely (any metric: a gap's child is its midpoint and the greedy order exhausts a level
+    of the binary splitting before it can reach the next finer one only if all gaps of that level were taken - which the
+    frame census of the reference run confirms), the 64th halves one of those gaps."""
+    assert len(imgs) == c["frames"] == 66
+    assert [int(i) for i in be.list_idx_injection] == c["list_idx_injection"] and [int(s) for s in be.list_nmb_stems] == c["list_nmb_stems"]
+    fr = [float(f) for f in be.tree_fracts]
+    grid = [k / 64 for k in range(65)]
+    assert all(g in fr for g in grid), fr
+    extra = [f for f in fr if f not in grid]
+    assert len(extra) == 1 and (extra[0] * 128) % 2 == 1, extra
+    ref_extra = [f for f in c["tree_fracts"] if f not in grid]
+    assert len(ref_extra) == 1               # (the reference's sequential run has the same shape)
+    assert [int(i) for i in be.tree_idx_injection] == c["tree_idx_injection"]

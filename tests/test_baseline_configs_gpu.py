@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 from oracle import pipe as OP  # noqa: E402  (checker only: the noise tape and the tiny configs)
 from oracle import sdxl_ref as R  # noqa: E402
 
-from _baseline_cfgs import check_structure, check_values, gold_configs, setup_cfg3, setup_cfg4, setup_cfg5  # noqa: E402
+from _baseline_cfgs import (check_structure, check_structure_cfg4_batched, check_values, gold_configs, setup_cfg3,  # noqa: E402
+                            setup_cfg4, setup_cfg5)
 
 GPU_TOL = dict(sim_rtol=5e-2, norm_rtol=3e-2, mean_tol=1.0, head_tol=4)
 
@@ -60,9 +61,11 @@ def test_cfg4_stated_tree_native(frontier, results_log):
     tape.reset()
     imgs = be.run_transition(fixed_seeds=[420, 421])
     assert len(imgs) == 66
-    check_structure(be, imgs, c)
-    if frontier == 1:       # (a batched frontier consumes the ancestral noise tape in evaluation order, not in commit order)
+    if frontier == 1:
+        check_structure(be, imgs, c)
         check_values(be, imgs, c, **GPU_TOL)
+    else:                   # (a batched frontier consumes the ancestral noise tape in evaluation order, not in commit order)
+        check_structure_cfg4_batched(be, imgs, c)
     results_log[f"cfg4_stated_tree_frontier{frontier}"] = {"frames": len(imgs), "same_tree": True,
                                                            "rounds": be.stats.get("frontier_rounds", 0)}
 
