@@ -126,7 +126,7 @@ typedef struct LbGemmParams {
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
-void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5, 7 (192x128) or 9 (ping-pong 256x256, gemm_pp.hip) and split-K */
+void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5, 7 (192x128), 9 (ping-pong 256x256, gemm_pp.hip) or 10 (one wave per SIMD, gemm_w4.hip) and split-K */
 void lb_gemm_pp_set_tuning(int prio, int mode);  /* tuning of the ping-pong kernel: s_setprio 1 around its MFMA clusters (default 1); mode 1 = one barrier per phase (default), 0 = two */
 void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */
 int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /* the tile (1..5) / split-K / grid lb_gemm_f16 would use; launches nothing */
