@@ -38,7 +38,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define PP_BK 64
 #define PP_SLOT_H 8192           // halves per half-tile slot: 128 rows x 64 halves = 16 KiB
-#define PP_LDS_BYTES (8 * PP_SLOT_H * 2)
 
 template <int V> struct PPInt { static constexpr int value = V; };
 typedef PPInt<0> J0; typedef PPInt<1> J1; typedef PPInt<2> J2; typedef PPInt<3> J3;
@@ -46,19 +45,23 @@ typedef PPInt<0> J0; typedef PPInt<1> J1; typedef PPInt<2> J2; typedef PPInt<3> 
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// PRIO: s_setprio 1 around the MFMA clusters (the partner wave's load segment then never delays an MFMA issue)
 // MODE 0: TWO barriers per phase - load segment | barrier | compute segment | barrier, the second group one barrier late.
 // MODE 1: ONE barrier per phase.  Between two barriers the early group (wr = 0) runs [compute phase k, load phase k + 1]
 //         while the late group (wr = 1) runs [load phase k, compute phase k]: the roles still alternate inside the interval
 //         (matrix beside memory, then memory beside matrix), but the hand-over in the middle is not a rendezvous - the late
 //         group's MFMAs simply follow the early group's through the SIMD's matrix pipe - and only half as many
 //         workgroup-wide synchronisations are paid per K-tile.  The early group reads a half-tile one interval BEFORE the
-//         late group does, so (RAW) the late group waits for its part of a half-tile one phase earlier (vmcnt(6) instead of
-//         vmcnt(8): three half-tiles instead of four may still be in flight at its wait); WAR is unchanged (a slot is
-//         requested again by load segment p, its last read belongs to phase <= p - 2, i.e. to an EARLIER interval for
-//         both groups, and the reads issued at the end of an interval are waited for by their own wave before it computes).
-template <bool GEGLU, bool PRIO, int MODE>
+//         late group does, so (RAW) the late group waits for its part of a half-tile one phase earlier (one half-tile fewer
+//         may still be in flight at its wait); WAR is unchanged (a slot is requested again by load segment p, its last read
+//         belongs to phase <= p - 2, i.e. to an EARLIER interval for both groups, and the reads issued at the end of an
+//         interval are waited for by their own wave before it computes).
+// NS = ring slots of 16 KiB (8 = 128 KiB, 10 = the whole 160 KiB LDS), D = half-tiles requested ahead of the consumer
+// (<= NS - 2).  Half-tile h = 4 t + J (J = 0 A0, 1 B0, 2 B1, 3 A1 of K-tile t) lives in slot h mod NS; load segment p
+// requests half-tile p + D.  At a wait D - 2 (late group of MODE 1: D - 3) half-tiles stay in flight.
+template <bool GEGLU, int NS, int D, int MODE>
 __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) {
+    static_assert(D >= 4 && D <= NS - 2, "a slot is requested again two phases after its only read");
+    constexpr bool PRIO = true;          // s_setprio 1 around the MFMA clusters (measured neutral: profiles/r04_gemm_bench_call2.txt)
     constexpr int BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
 
@@ -130,20 +133,26 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     const char* const a_base = reinterpret_cast<const char*>(p.A) + (long)kt_begin * (PP_BK * 2);
     const char* const w_base = reinterpret_cast<const char*>(p.W) + (long)kt_begin * (PP_BK * 2);
 
-    // request half-tile J (0 = A0, 1 = B0, 2 = B1, 3 = A1) of K-tile `tile` (of this block's range) into ring slot 4*(tile & 1) + J
+    // ring slot (in halves) of half-tile J of K-tile `tile`
+    auto slot_of = [&](int tile, int J) { return ((4 * tile + J) % NS) * PP_SLOT_H; };
+    // request half-tile J (0 = A0, 1 = B0, 2 = B1, 3 = A1) of K-tile `tile` (of this block's range) into its ring slot
     auto stage = [&](auto jc, int tile) {
         constexpr int J = decltype(jc)::value;
         constexpr bool IS_A = (J == 0 || J == 3);
         constexpr int Q = (J == 0 || J == 1) ? 0 : 1;                 // qm for A, qn for B
-        const int d = tile & 1;
         const int kt = tile < nkt ? tile : nkt - 1;
         const long koff = (long)kt * (PP_BK * 2);                     // scalar
-        f16* base = lds + (4 * d + J) * PP_SLOT_H + (wave * 8) * PP_BK;
+        f16* base = lds + slot_of(tile, J) + (wave * 8) * PP_BK;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const char* src = (IS_A ? a_base : w_base) + koff + (size_t)(IS_A ? a_off[Q * 2 + n] : w_off[Q * 2 + n]);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + n * 64 * PP_BK), 16, 0, 0);
         }
+    };
+    // load segment of phase (t, I) requests half-tile 4 t + I + D
+    auto stage_ahead = [&](auto ic, int t) {
+        constexpr int I = decltype(ic)::value, JJ = (I + D) & 3, DT = (I + D) >> 2;
+        stage(PPInt<JJ>{}, t + DT);
     };
 
     // ---- fragment reads: lane (g, l16) reads row (16 i + l16) at 16-B chunk (4 ks + g) ^ (row & 7) ----
@@ -157,21 +166,19 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     }
     f16x8 af[4][2];                  // [i][ks]   rows qm*64 + 16 i of the wave's 128
     f16x8 b0[2][2], b1[2][2];        // [jj][ks]  columns qn*32 + 16 jj of the wave's 64
-    auto read_a = [&](auto jc, int doff) {
-        constexpr int J = decltype(jc)::value;
+    auto read_a = [&](int soff) {        // soff = slot_of(t, J)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                af[i][ks] = *reinterpret_cast<const f16x8*>(a_rd[ks] + doff + J * PP_SLOT_H + i * 16 * PP_BK);
+                af[i][ks] = *reinterpret_cast<const f16x8*>(a_rd[ks] + soff + i * 16 * PP_BK);
     };
-    auto read_b = [&](auto jc, int doff, f16x8 (&bf)[2][2]) {
-        constexpr int J = decltype(jc)::value;
+    auto read_b = [&](int soff, f16x8 (&bf)[2][2]) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
-                bf[jj][ks] = *reinterpret_cast<const f16x8*>(b_rd[ks] + doff + J * PP_SLOT_H + jj * 16 * PP_BK);
+                bf[jj][ks] = *reinterpret_cast<const f16x8*>(b_rd[ks] + soff + jj * 16 * PP_BK);
     };
 
     f32x4 acc[8][4];
@@ -194,39 +201,37 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
-    // ---- prologue: half-tiles 0..5 (K-tile 0 whole, A0 / B0 of K-tile 1) ----
-    stage(J0{}, 0);
-    stage(J1{}, 0);
-    stage(J2{}, 0);
-    stage(J3{}, 0);
-    stage(J0{}, 1);
-    stage(J1{}, 1);
-    pp_wait_vm<8>();                         // A0 / B0 of K-tile 0 have landed (this wave's part)
+    // ---- prologue: half-tiles 0 .. D-1 ----
+    {
+        auto pro = [&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            if constexpr (H < D) stage(PPInt<(H & 3)>{}, H >> 2);
+        };
+        pro(PPInt<0>{}); pro(PPInt<1>{}); pro(PPInt<2>{}); pro(PPInt<3>{}); pro(PPInt<4>{}); pro(PPInt<5>{});
+        pro(PPInt<6>{}); pro(PPInt<7>{}); pro(PPInt<8>{}); pro(PPInt<9>{});
+    }
+    pp_wait_vm<2 * (D - 2)>();               // A0 / B0 of K-tile 0 have landed (this wave's part)
     pp_barrier();
 
-    // load segments of the four phases of K-tile t (d = t & 1; VM = the vmcnt this group waits for, -1 = none)
-    auto load0 = [&](int t, auto vm) {       // reads A0, B0; requests B1 of K-tile t + 1
-        const int d = t & 1;
-        read_b(J1{}, d * 4 * PP_SLOT_H, b0);
-        read_a(J0{}, d * 4 * PP_SLOT_H);
-        stage(J2{}, t + 1);
+    // load segments of the four phases of K-tile t (VM = the vmcnt this group waits for, -1 = none)
+    auto load0 = [&](int t, auto vm) {       // reads A0, B0
+        read_b(slot_of(t, 1), b0);
+        read_a(slot_of(t, 0));
+        stage_ahead(J0{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
-    auto load1 = [&](int t, auto vm) {       // reads B1; requests A1 of K-tile t + 1
-        const int d = t & 1;
-        read_b(J2{}, d * 4 * PP_SLOT_H, b1);
-        stage(J3{}, t + 1);
+    auto load1 = [&](int t, auto vm) {       // reads B1
+        read_b(slot_of(t, 2), b1);
+        stage_ahead(J1{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
-    auto load2 = [&](int t, auto vm) {       // reads A1; requests A0 of K-tile t + 2
-        const int d = t & 1;
-        read_a(J3{}, d * 4 * PP_SLOT_H);
-        stage(J0{}, t + 2);
+    auto load2 = [&](int t, auto vm) {       // reads A1
+        read_a(slot_of(t, 3));
+        stage_ahead(J2{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
-    auto load3 = [&](int t, auto vm) {       // reads nothing (B0 stayed in registers); requests B0 of K-tile t + 2
-        const int d = t & 1;
-        stage(J1{}, t + 2);
+    auto load3 = [&](int t, auto vm) {       // reads nothing (B0 stayed in registers)
+        stage_ahead(J3{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto compute = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2]) {
@@ -235,8 +240,8 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         __builtin_amdgcn_sched_barrier(0);
     };
     typedef PPInt<-1> NOWAIT;
-    typedef PPInt<8> VM8;
-    typedef PPInt<6> VM6;
+    typedef PPInt<2 * (D - 2)> VM8;      // (names from the D = 6 ring: 8 / 6 requests = 4 / 3 half-tiles in flight at a wait)
+    typedef PPInt<2 * (D - 3)> VM6;
 
     if constexpr (MODE == 0) {
         if (wr == 1) pp_barrier();           // the second group runs one barrier interval behind the first
@@ -281,7 +286,7 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         }
     } else {
         // late group: [load phase k | compute phase k] per interval; its waits cover what the EARLY group reads in the next interval
-        pp_wait_vm<6>();                     // B1 of K-tile 0 (the early group reads it in interval 0)
+        pp_wait_vm<2 * (D - 3)>();           // B1 of K-tile 0 (the early group reads it in interval 0)
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nkt; ++t) {
@@ -319,34 +324,33 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     lb_gemm_tile_epilogue<8, 4, GEGLU>(p, acc, m0 + wr * 128 + l16, n0 + wc * 64 + 4 * g, n0 + wc * 32 + 4 * g);
 }
 
-static int g_pp_prio = 1, g_pp_mode = 1;
-extern "C" void lb_gemm_pp_set_tuning(int prio, int mode) { g_pp_prio = prio; g_pp_mode = mode; }
+static int g_pp_ring = 0, g_pp_mode = 1;      // ring: 0 = 8 slots / 6 ahead, 1 = 10 slots (160 KiB) / 8 ahead, 2 = 8 slots / 4 ahead (study)
+extern "C" void lb_gemm_pp_set_tuning(int ring, int mode) { g_pp_ring = ring; g_pp_mode = mode; }
 
 int lb_gemm_pp_eligible(const LbGemmParams& p) {
     return !p.conv && p.K % PP_BK == 0 && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_CH_STATS)) && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
            (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);       // 32-bit row offsets
 }
 
-template <bool GEGLU, bool PRIO, int MODE>
+template <bool GEGLU, int NS, int D, int MODE>
 static void pp_launch(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+    constexpr int BYTES = NS * PP_SLOT_H * 2;
     static unsigned long long seen = 0;
     if (lb_first_call_on_device(seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU, PRIO, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
-    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU, PRIO, MODE>), grid, dim3(512), PP_LDS_BYTES, stream, p);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU, NS, D, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU, NS, D, MODE>), grid, dim3(512), BYTES, stream, p);
+}
+
+template <bool GEGLU>
+static void pp_launch_ring(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+    if (g_pp_mode == 0) return pp_launch<GEGLU, 8, 6, 0>(p, grid, stream);
+    if (g_pp_ring == 1) return pp_launch<GEGLU, 10, 8, 1>(p, grid, stream);
+    if (g_pp_ring == 2) return pp_launch<GEGLU, 8, 4, 1>(p, grid, stream);
+    return pp_launch<GEGLU, 8, 6, 1>(p, grid, stream);
 }
 
 int lb_gemm_launch_pp(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
-    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;
-    const int key = (geglu ? 4 : 0) | (g_pp_prio ? 2 : 0) | (g_pp_mode ? 1 : 0);
-    switch (key) {
-        case 0: pp_launch<false, false, 0>(p, grid, stream); break;
-        case 1: pp_launch<false, false, 1>(p, grid, stream); break;
-        case 2: pp_launch<false, true, 0>(p, grid, stream); break;
-        case 3: pp_launch<false, true, 1>(p, grid, stream); break;
-        case 4: pp_launch<true, false, 0>(p, grid, stream); break;
-        case 5: pp_launch<true, false, 1>(p, grid, stream); break;
-        case 6: pp_launch<true, true, 0>(p, grid, stream); break;
-        default: pp_launch<true, true, 1>(p, grid, stream); break;
-    }
+    if (p.flags & LB_GEMM_GEGLU) pp_launch_ring<true>(p, grid, stream);
+    else pp_launch_ring<false>(p, grid, stream);
     return 0;
 }

@@ -786,11 +786,12 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
 PP_SHAPES = [(4352, 1280, 1280), (512, 768, 640), (300, 260, 128), (1000, 3840, 64), (256, 256, 192), (4352, 512, 5120)]
 
 
-@pytest.mark.parametrize("prio,mode", [(1, 1), (0, 1), (1, 0)])
+@pytest.mark.parametrize("ring,mode", [(0, 1), (1, 1), (2, 1), (0, 0)])
 @pytest.mark.parametrize("shape", PP_SHAPES)
-def test_gemm_pingpong(shape, prio, mode, results_log):
+def test_gemm_pingpong(shape, ring, mode, results_log):
     """gemm_pp.hip against the fp32 reference AND bit for bit against the lock-step tiles (same K order per accumulator);
-    mode 1 = one barrier per phase (default), 0 = two; ragged M / N (rows beyond the edge re-read the last valid row), K = 64 (one K-tile: prologue + drain only), an odd number of K-tiles,
+    ring 0 = 8 slots / 6 half-tiles ahead, 1 = 10 slots (the whole 160 KiB LDS) / 8 ahead, 2 = 8 slots / 4 ahead; mode 1 = one barrier
+    per phase (default), 0 = two; ragged M / N (rows beyond the edge re-read the last valid row), K = 64 (one K-tile: prologue + drain only), an odd number of K-tiles,
     bias / residual epilogue.  Repeated launches: a staging race would show as run-to-run differences."""
     o, l = ops(), lib()
     M, N, K = shape
@@ -802,12 +803,12 @@ def test_gemm_pingpong(shape, prio, mode, results_log):
     try:
         lock_step = o.gemm(Ad, Wd, bias=bd, residual=rd)
         l.api.lb_gemm_set_tuning(9, 1)
-        l.api.lb_gemm_pp_set_tuning(prio, mode)
+        l.api.lb_gemm_pp_set_tuning(ring, mode)
         runs = [o.gemm(Ad, Wd, bias=bd, residual=rd) for _ in range(6)]
     finally:
         l.api.lb_gemm_set_tuning(0, 0)
-        l.api.lb_gemm_pp_set_tuning(1, 1)
-    check_close(results_log, f"pp_gemm_{M}x{N}x{K}_prio{prio}_mode{mode}", runs[0], ref)
+        l.api.lb_gemm_pp_set_tuning(0, 1)
+    check_close(results_log, f"pp_gemm_{M}x{N}x{K}_ring{ring}_mode{mode}", runs[0], ref)
     assert torch.equal(runs[0], lock_step)
     for r in runs[1:]:
         assert torch.equal(r, runs[0])
