@@ -58,9 +58,15 @@ __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "mem
 // NS = ring slots of 16 KiB (8 = 128 KiB, 10 = the whole 160 KiB LDS), D = half-tiles requested ahead of the consumer
 // (<= NS - 2).  Half-tile h = 4 t + J (J = 0 A0, 1 B0, 2 B1, 3 A1 of K-tile t) lives in slot h mod NS; load segment p
 // requests half-tile p + D.  At a wait D - 2 (late group of MODE 1: D - 3) half-tiles stay in flight.
-template <bool GEGLU, int NS, int D, int MODE>
+// SIC (MODE 1 only): the two LDS-DMA requests of a phase are issued INSIDE its compute segment, between the MFMAs (which
+// leave 12 of every 16 issue cycles free), instead of in the load segment - the load segments, whose length decides whether
+// the partner's MFMAs start on time, then hold LDS reads only.  A request issued in compute segment p comes one barrier
+// later than one issued in load segment p, so the ring may run one half-tile further ahead (D <= NS - 1: the slot's last
+// read belongs to phase <= p - 1 and has returned before the barrier that opens the requesting interval).
+template <bool GEGLU, int NS, int D, int MODE, bool SIC = false>
 __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) {
-    static_assert(D >= 4 && D <= NS - 2, "a slot is requested again two phases after its only read");
+    static_assert(D >= 4 && D <= NS - 2 + (SIC ? 1 : 0), "a slot is requested again two phases after its only read");
+    static_assert(!SIC || MODE == 1, "requests inside the compute segment: one-barrier form only");
     constexpr bool PRIO = true;          // s_setprio 1 around the MFMA clusters (measured neutral: profiles/r04_gemm_bench_call2.txt)
     constexpr int BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
@@ -149,6 +155,16 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + n * 64 * PP_BK), 16, 0, 0);
         }
     };
+    auto stage_half = [&](auto jc, int tile, int n) {          // instruction n (0 / 1) of that request
+        constexpr int J = decltype(jc)::value;
+        constexpr bool IS_A = (J == 0 || J == 3);
+        constexpr int Q = (J == 0 || J == 1) ? 0 : 1;
+        const int kt = tile < nkt ? tile : nkt - 1;
+        const long koff = (long)kt * (PP_BK * 2);
+        f16* base = lds + slot_of(tile, J) + (wave * 8) * PP_BK + n * 64 * PP_BK;
+        const char* src = (IS_A ? a_base : w_base) + koff + (size_t)(IS_A ? a_off[Q * 2 + (n & 1)] : w_off[Q * 2 + (n & 1)]);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)base, 16, 0, 0);
+    };
     // load segment of phase (t, I) requests half-tile 4 t + I + D
     auto stage_ahead = [&](auto ic, int t) {
         constexpr int I = decltype(ic)::value, JJ = (I + D) & 3, DT = (I + D) >> 2;
@@ -187,17 +203,27 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto mma = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2]) {
-        constexpr int QM = decltype(qmc)::value, QN = decltype(qnc)::value;
+    // the 16 MFMAs of one phase; with SIC the phase's two requests go between them (after the 4th and the 12th)
+    auto mma = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2], auto ic, int t) {
+        constexpr int QM = decltype(qmc)::value, QN = decltype(qnc)::value, I = decltype(ic)::value;
+        constexpr int JJ = (I + D) & 3, DT = (I + D) >> 2;           // compute segment (t, I) requests half-tile 4 t + I + D
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     acc[QM * 4 + i][QN * 2 + jj] =
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jj][ks], af[i][ks], acc[QM * 4 + i][QN * 2 + jj], 0, 0, 0);
+                if constexpr (SIC) {
+                    if (i == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        stage_half(PPInt<JJ>{}, t + DT, ks);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -217,31 +243,32 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     auto load0 = [&](int t, auto vm) {       // reads A0, B0
         read_b(slot_of(t, 1), b0);
         read_a(slot_of(t, 0));
-        stage_ahead(J0{}, t);
+        if constexpr (!SIC) stage_ahead(J0{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto load1 = [&](int t, auto vm) {       // reads B1
         read_b(slot_of(t, 2), b1);
-        stage_ahead(J1{}, t);
+        if constexpr (!SIC) stage_ahead(J1{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto load2 = [&](int t, auto vm) {       // reads A1
         read_a(slot_of(t, 3));
-        stage_ahead(J2{}, t);
+        if constexpr (!SIC) stage_ahead(J2{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto load3 = [&](int t, auto vm) {       // reads nothing (B0 stayed in registers)
-        stage_ahead(J3{}, t);
+        if constexpr (!SIC) stage_ahead(J3{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
-    auto compute = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2]) {
+    auto compute = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2], auto ic, int t) {
         __builtin_amdgcn_sched_barrier(0);
-        mma(qmc, qnc, bf);
+        mma(qmc, qnc, bf, ic, t);
         __builtin_amdgcn_sched_barrier(0);
     };
     typedef PPInt<-1> NOWAIT;
-    typedef PPInt<2 * (D - 2)> VM8;      // (names from the D = 6 ring: 8 / 6 requests = 4 / 3 half-tiles in flight at a wait)
-    typedef PPInt<2 * (D - 3)> VM6;
+    constexpr int S = SIC ? 1 : 0;       // (with SIC a load segment comes BEFORE its phase's requests)
+    typedef PPInt<2 * (D - 2 - S)> VM8;  // (names from the D = 6 ring: 8 / 6 requests = 4 / 3 half-tiles in flight at a wait)
+    typedef PPInt<2 * (D - 3 - S)> VM6;
 
     if constexpr (MODE == 0) {
         if (wr == 1) pp_barrier();           // the second group runs one barrier interval behind the first
@@ -249,19 +276,19 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         for (int t = 0; t < nkt; ++t) {
             load0(t, VM8{});                 // ... B1 of this K-tile landed
             pp_barrier();
-            compute(J0{}, J0{}, b0);
+            compute(J0{}, J0{}, b0, J0{}, t);
             pp_barrier();
             load1(t, VM8{});                 // ... A1 of this K-tile landed
             pp_barrier();
-            compute(J0{}, J1{}, b1);
+            compute(J0{}, J1{}, b1, J1{}, t);
             pp_barrier();
             load2(t, NOWAIT{});
             pp_barrier();
-            compute(J1{}, J1{}, b1);
+            compute(J1{}, J1{}, b1, J2{}, t);
             pp_barrier();
             load3(t, VM8{});                 // ... A0 / B0 of the next K-tile landed
             pp_barrier();
-            compute(J1{}, J0{}, b0);
+            compute(J1{}, J0{}, b0, J3{}, t);
             pp_barrier();
         }
         if (wr == 0) pp_barrier();           // pairs with the late group's last barrier
@@ -271,16 +298,16 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nkt; ++t) {
-            compute(J0{}, J0{}, b0);
+            compute(J0{}, J0{}, b0, J0{}, t);
             load1(t, VM8{});
             pp_barrier();
-            compute(J0{}, J1{}, b1);
+            compute(J0{}, J1{}, b1, J1{}, t);
             load2(t, NOWAIT{});
             pp_barrier();
-            compute(J1{}, J1{}, b1);
+            compute(J1{}, J1{}, b1, J2{}, t);
             load3(t, VM8{});
             pp_barrier();
-            compute(J1{}, J0{}, b0);
+            compute(J1{}, J0{}, b0, J3{}, t);
             load0(t + 1, VM8{});             // (past the last K-tile: reads of stale slots into dead registers)
             pp_barrier();
         }
@@ -291,16 +318,16 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nkt; ++t) {
             load0(t, VM6{});                 // ... A1 of this K-tile landed
-            compute(J0{}, J0{}, b0);
+            compute(J0{}, J0{}, b0, J0{}, t);
             pp_barrier();
             load1(t, NOWAIT{});
-            compute(J0{}, J1{}, b1);
+            compute(J0{}, J1{}, b1, J1{}, t);
             pp_barrier();
             load2(t, VM6{});                 // ... A0 / B0 of the next K-tile landed
-            compute(J1{}, J1{}, b1);
+            compute(J1{}, J1{}, b1, J2{}, t);
             pp_barrier();
             load3(t, VM6{});                 // ... B1 of the next K-tile landed
-            compute(J1{}, J0{}, b0);
+            compute(J1{}, J0{}, b0, J3{}, t);
             pp_barrier();
         }
     }
@@ -324,7 +351,7 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     lb_gemm_tile_epilogue<8, 4, GEGLU>(p, acc, m0 + wr * 128 + l16, n0 + wc * 64 + 4 * g, n0 + wc * 32 + 4 * g);
 }
 
-static int g_pp_ring = 0, g_pp_mode = 1;      // ring: 0 = 8 slots / 6 ahead, 1 = 10 slots (160 KiB) / 8 ahead, 2 = 8 slots / 4 ahead (study)
+static int g_pp_ring = 0, g_pp_mode = 1;      // ring: 0 = 8 slots / 6 ahead, 1 = 10 slots (160 KiB) / 8 ahead, 2 = 8 slots / 4 ahead (study), 3 = 8 slots / 7 ahead with the requests inside the compute segments
 extern "C" void lb_gemm_pp_set_tuning(int ring, int mode) { g_pp_ring = ring; g_pp_mode = mode; }
 
 int lb_gemm_pp_eligible(const LbGemmParams& p) {
@@ -332,13 +359,13 @@ int lb_gemm_pp_eligible(const LbGemmParams& p) {
            (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);       // 32-bit row offsets
 }
 
-template <bool GEGLU, int NS, int D, int MODE>
+template <bool GEGLU, int NS, int D, int MODE, bool SIC = false>
 static void pp_launch(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     constexpr int BYTES = NS * PP_SLOT_H * 2;
     static unsigned long long seen = 0;
     if (lb_first_call_on_device(seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU, NS, D, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU, NS, D, MODE>), grid, dim3(512), BYTES, stream, p);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU, NS, D, MODE, SIC>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU, NS, D, MODE, SIC>), grid, dim3(512), BYTES, stream, p);
 }
 
 template <bool GEGLU>
@@ -346,6 +373,7 @@ static void pp_launch_ring(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     if (g_pp_mode == 0) return pp_launch<GEGLU, 8, 6, 0>(p, grid, stream);
     if (g_pp_ring == 1) return pp_launch<GEGLU, 10, 8, 1>(p, grid, stream);
     if (g_pp_ring == 2) return pp_launch<GEGLU, 8, 4, 1>(p, grid, stream);
+    if (g_pp_ring == 3) return pp_launch<GEGLU, 8, 7, 1, true>(p, grid, stream);
     return pp_launch<GEGLU, 8, 6, 1>(p, grid, stream);
 }
 

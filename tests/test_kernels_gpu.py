@@ -786,11 +786,11 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
 PP_SHAPES = [(4352, 1280, 1280), (512, 768, 640), (300, 260, 128), (1000, 3840, 64), (256, 256, 192), (4352, 512, 5120)]
 
 
-@pytest.mark.parametrize("ring,mode", [(0, 1), (1, 1), (2, 1), (0, 0)])
+@pytest.mark.parametrize("ring,mode", [(0, 1), (1, 1), (2, 1), (3, 1), (0, 0)])
 @pytest.mark.parametrize("shape", PP_SHAPES)
 def test_gemm_pingpong(shape, ring, mode, results_log):
     """gemm_pp.hip against the fp32 reference AND bit for bit against the lock-step tiles (same K order per accumulator);
-    ring 0 = 8 slots / 6 half-tiles ahead, 1 = 10 slots (the whole 160 KiB LDS) / 8 ahead, 2 = 8 slots / 4 ahead; mode 1 = one barrier
+    ring 0 = 8 slots / 6 half-tiles ahead, 1 = 10 slots (the whole 160 KiB LDS) / 8 ahead, 2 = 8 slots / 4 ahead, 3 = 8 slots / 7 ahead with the requests issued inside the compute segments; mode 1 = one barrier
     per phase (default), 0 = two; ragged M / N (rows beyond the edge re-read the last valid row), K = 64 (one K-tile: prologue + drain only), an odd number of K-tiles,
     bias / residual epilogue.  Repeated launches: a staging race would show as run-to-run differences."""
     o, l = ops(), lib()

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     if (set == "b17" || set == "all") shapes.insert(shapes.end(), std::begin(B17), std::end(B17));
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
-    const Variant all_variants[] = {{"auto", 0, 0, 0, 1}, {"pp-m1", 9, 1, 0, 1}, {"pp-r10", 9, 1, 1, 1}, {"pp-d4", 9, 1, 2, 1}, {"pp-m0", 9, 1, 0, 0},
+    const Variant all_variants[] = {{"auto", 0, 0, 0, 1}, {"pp-m1", 9, 1, 0, 1}, {"pp-r10", 9, 1, 1, 1}, {"pp-d4", 9, 1, 2, 1}, {"pp-sic", 9, 1, 3, 1}, {"pp-m0", 9, 1, 0, 0},
                                     {"w4", 10, 1, 0, 1}, {"t5", 5, 1, 0, 1}, {"t4", 4, 1, 0, 1}, {"t1", 1, 1, 0, 1}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
