@@ -88,9 +88,24 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const bool w_dominant = n_eff > p.M;
-    const int block_n = w_dominant ? bid / m_blocks : bid % n_blocks;
-    const int block_m = w_dominant ? bid % m_blocks : bid / n_blocks;
+    // Tile order inside an XCD's run.  The ~32 tiles an XCD works on at a time share its 4 MiB L2: as a 1 x 32 strip they
+    // pull 33 operand panels through it per K-tile, as a GM x (32 / GM) patch only GM + 32 / GM (12 for GM = 4).  p.reserved_
+    // = GM > 0: walk GM block rows down, then the next block column ("grouped" order); 0: the strip order of the other
+    // kernels (the operand with more bytes is the shared one).
+    int block_m, block_n;
+    if (p.reserved_ > 0) {
+        const int gm = p.reserved_;
+        const int per_group = gm * n_blocks;
+        const int group = bid / per_group, first_m = group * gm;
+        const int rows = m_blocks - first_m < gm ? m_blocks - first_m : gm;
+        const int in_group = bid - group * per_group;
+        block_m = first_m + in_group % rows;
+        block_n = in_group / rows;
+    } else {
+        const bool w_dominant = n_eff > p.M;
+        block_n = w_dominant ? bid / m_blocks : bid % n_blocks;
+        block_m = w_dominant ? bid % m_blocks : bid / n_blocks;
+    }
     const int m0 = block_m * BM;
     const int n0 = block_n * BN_OUT;
 
@@ -377,7 +392,12 @@ static void pp_launch_ring(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     return pp_launch<GEGLU, 8, 6, 1>(p, grid, stream);
 }
 
-int lb_gemm_launch_pp(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+static int g_pp_group = 0;
+extern "C" void lb_gemm_pp_set_group(int gm) { g_pp_group = gm; }
+
+int lb_gemm_launch_pp(const LbGemmParams& pin, dim3 grid, hipStream_t stream) {
+    LbGemmParams p = pin;
+    p.reserved_ = g_pp_group;
     if (p.flags & LB_GEMM_GEGLU) pp_launch_ring<true>(p, grid, stream);
     else pp_launch_ring<false>(p, grid, stream);
     return 0;

@@ -70,7 +70,8 @@ SIGNATURES = {
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
     "lb_gemm_set_wide_store": (None, [_i]),
-    "lb_gemm_pp_set_tuning": (None, [_i, _i]),
+    "lb_gemm_pp_set_tuning", "lb_gemm_pp_set_group": (None, [_i, _i]),
+    "lb_gemm_pp_set_group": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_conv3x3_narrow_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
@@ -123,7 +124,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_tuning", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_tuning", "lb_gemm_pp_set_group", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 
