@@ -70,7 +70,7 @@ SIGNATURES = {
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
     "lb_gemm_set_wide_store": (None, [_i]),
-    "lb_gemm_pp_set_tuning", "lb_gemm_pp_set_group": (None, [_i, _i]),
+    "lb_gemm_pp_set_tuning": (None, [_i, _i]),
     "lb_gemm_pp_set_group": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
     "lb_conv3x3_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
