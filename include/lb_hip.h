@@ -127,6 +127,7 @@ typedef struct LbGemmParams {
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
 void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5, 7 (192x128), 9 (ping-pong 256x256, gemm_pp.hip) or 10 (one wave per SIMD, gemm_w4.hip) and split-K */
+void lb_gemm_set_pp_auto(int on);                 /* A/B studies: 0 = the automatic tile policy never picks the ping-pong kernel (default 1) */
 void lb_gemm_pp_set_group(int gm);                /* tuning: tile order of the ping-pong kernel inside an XCD's run: gm block rows down, then the next block column (0 = strip order) */
 void lb_gemm_pp_set_tuning(int ring, int mode);  /* tuning of the ping-pong kernel: ring 0 = 8 slots / 6 half-tiles ahead (default), 1 = 10 slots (160 KiB) / 8 ahead, 2 = 8 slots / 4 ahead (study); mode 1 = one barrier per phase (default), 0 = two */
 void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */

@@ -312,6 +312,8 @@ static void launch_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     }
 }
 
+static int g_pp_auto = 1;          // 0: the automatic policy never picks the ping-pong kernel (A/B studies: lb_gemm_set_pp_auto)
+extern "C" void lb_gemm_set_pp_auto(int on) { g_pp_auto = on; }
 static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64, direct-to-LDS only: 4=256x128 5=256x256 7=192x128
 static int g_force_splitk = 0;    // 0 auto
 static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
@@ -468,7 +470,18 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
             }
         }
     }
-    if (tile >= 4 && tile < 9 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;   // 6- / 8-wave tiles: direct-to-LDS family only
+    if (tile >= 4 && tile < 9 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;
+    // Ping-pong 256x256 loop (gemm_pp.hip): 1.15-1.27x the lock-step 8-wave tiles wherever 256-wide tiles fill the chip and
+    // the K loop is long enough to pay for its deeper prologue - on the B = 17 programs the GEGLU projections (M 4352 /
+    // 17408), the fused q|k|v projection, the 640-wide feed-forward output and the per-branch context projection
+    // (profiles/r04_gemm_bench_call6.txt).  Shapes with ~1/3 of the chip in 256x256 tiles (N = 1280 at M = 4352), and K = 640
+    // unless the grid runs for several rounds, stay on the smaller lock-step tiles.
+    if (!g_force_tile && g_pp_auto && lb_gemm_pp_eligible(p)) {
+        const int bn_out = geglu ? 128 : 256;
+        const long n_pad = (long)((n_eff + bn_out - 1) / bn_out) * bn_out;
+        const long b9 = blocks(256, 256);
+        if (b9 >= 192 && (p.K >= 1024 || b9 >= 1024) && n_pad * 4 <= (long)n_eff * 5) tile = 9;
+    }   // 6- / 8-wave tiles: direct-to-LDS family only
     // long-K problems with 1-2.5 small tiles per CU (B=2 convs of the UNet: M=2048, N=640, K=5760): no split
     // is possible at 64x64 (> 256 blocks), so they crawl through ~90 K-tiles per block.  Take 128x64 tiles
     // (half the blocks) and let the split-K rule below spread K instead.
@@ -494,6 +507,7 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         }
         if (splitk > k_tiles) splitk = k_tiles;
         if (splitk < 1) splitk = 1;
+        if (tile == 9 && !g_force_splitk) splitk = 1;         // (the policy takes the ping-pong kernel only for chip-filling grids)
     }
     tile_out = tile;
     splitk_out = splitk;

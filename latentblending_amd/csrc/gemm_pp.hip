@@ -392,7 +392,7 @@ static void pp_launch_ring(const LbGemmParams& p, dim3 grid, hipStream_t stream)
     return pp_launch<GEGLU, 8, 6, 1>(p, grid, stream);
 }
 
-static int g_pp_group = 0;
+static int g_pp_group = 8;         // measured best of {0 (strips), 2, 4, 8} on the B = 17 shapes and the large squares (profiles/r04_gemm_bench_call6.txt)
 extern "C" void lb_gemm_pp_set_group(int gm) { g_pp_group = gm; }
 
 int lb_gemm_launch_pp(const LbGemmParams& pin, dim3 grid, hipStream_t stream) {

@@ -577,8 +577,9 @@ def test_synthetic_weight_streams_are_the_same_on_both_sides():
 
 def test_gemm_tile_policy_is_pinned():
     """lb_gemm_plan (pure host arithmetic of the launcher): the tile / split-K choices the MI355X sweeps led to
-    (profiles/r01_gemm_*.txt, tools/ab_policy.py) for the shapes the SDXL programs launch.  Tiles: 1 = 128x128,
-    2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves), 7 = 192x128 (6 waves)."""
+    (profiles/r01_gemm_*.txt, tools/ab_policy.py, profiles/r04_gemm_bench_call*.txt) for the shapes the SDXL programs launch.
+    Tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, lock-step), 7 = 192x128 (6 waves),
+    9 = 256x256 ping-pong (gemm_pp.hip)."""
     from latentblending_amd.hip import lib
 
     def plan(M, N, K, conv=False, geglu=False, ws=None, zero_page=True):
@@ -594,11 +595,16 @@ def test_gemm_tile_policy_is_pinned():
         return t.value, sk.value, nb.value
 
     # UNet at B=17 (M = 17*256 / 17*1024)
-    assert plan(4352, 10240, 1280, geglu=True)[:2] == (5, 1)            # GEGLU: 256x256, 680 blocks
+    assert plan(4352, 10240, 1280, geglu=True)[:2] == (9, 1)            # GEGLU: 256x256 ping-pong, 680 blocks
     assert plan(4352, 10240, 1280, geglu=True)[2] == 17 * 40
     assert plan(4352, 1280, 1280) == (7, 1, 230)                        # short K, 170 blocks of 256x128 = 2/3 of the chip: 230 of 192x128
     assert plan(4352, 1280, 5120)[:2] == (4, 1)
-    assert plan(4352, 2560, 1280)[:2] == (5, 1)                         # one round of 256x256 beats two of 256x128
+    assert plan(4352, 2560, 1280)[:2] == (5, 1)                         # one round of 256x256 beats two of 256x128 (170 tiles: lock-step form)
+    assert plan(4352, 3840, 1280) == (9, 1, 255)                        # fused q|k|v: one round of ping-pong tiles
+    assert plan(17408, 5120, 640, geglu=True)[0] == 9                   # K = 640 pays only over several rounds (1360 tiles) ...
+    assert plan(17408, 1920, 640)[0] != 9 and plan(17408, 640, 640)[0] != 9     # ... not over one or two
+    assert plan(17408, 640, 2560) == (9, 1, 204)                        # (no automatic split-K on the ping-pong kernel)
+    assert plan(1360, 166400, 2048)[0] == 9                             # per-branch context K|V projection
     assert plan(17408, 640, 640)[0] in (1, 2)                           # short K: 4-wave tiles
     assert plan(17408, 640, 5760, conv=True)[0] == 5
     assert plan(69632, 320, 2880, conv=True)[0] == 1                    # N = 320 pads badly to 256-wide tiles
@@ -627,7 +633,8 @@ def test_gemm_tile_policy_is_pinned():
     assert plan(2048, 640, 640) == (3, 1, 320)
     assert plan(512, 1280, 5120, ws=False)[1] == 1                      # no slab workspace -> never splits
     # without the zero page the direct-to-LDS family (and its 8-wave tiles) is not available
-    assert plan(4352, 10240, 1280, geglu=True, zero_page=False)[0] == 1
+    assert plan(4352, 1280, 5120, zero_page=False)[0] in (1, 2) and plan(4456448, 128, 1152, conv=True, zero_page=False)[0] == 1
+    assert plan(4352, 10240, 1280, geglu=True, zero_page=False)[0] == 9      # (the ping-pong kernel masks nothing: no zero page needed)
     # the study switches (arithmetic / policy A/B) are NOT part of the product library
     for name in ("lb_gemm_set_policy", "lb_slerp_set_study", "lb_conv_halo_set_study"):
         assert not hasattr(ctypes.CDLL(lib.LIB_PATH), name), f"{name} must only exist in -DLB_STUDY_BUILD libraries"

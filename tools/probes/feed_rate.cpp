@@ -34,14 +34,21 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // MODE 0 glds, 1 buffer..lds, 2 registers + ds_write.  One "tile" = one 16 KiB half-tile; the block's panel has 128 rows.
 template <int DEPTH, int MODE>
 __global__ void __launch_bounds__(512) feed_kernel(const char* base, long panel_stride, int panels_mod, int panel_div, long ld, int ntiles,
-                                                   float* sink) {
+                                                   float* sink, int gm = 0, int gn = 0) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int NS = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane >> 3, cl = (lane & 7) ^ (lr & 7);
-    const int panel = (blockIdx.x / panel_div) % panels_mod;
+    int panel = (blockIdx.x / panel_div) % panels_mod, panel_b = panel;
+    if (gm > 0) {                                // GEMM-like: the XCD's 32 blocks form a gm x gn patch; even half-tiles come from the block's A
+        const int x = blockIdx.x % 8, i = blockIdx.x / 8;      // panel (shared by gn blocks), odd ones from its W panel (shared by gm blocks)
+        panel = x * gm + i % gm;
+        panel_b = 8 * gm + x * gn + (i / gm) % gn;
+    }
     const char* pbase = base + (long)panel * panel_stride;
+    const long b_delta = (long)(panel_b - panel) * panel_stride;
+    const int tiles_per_row = (int)(ld / 128);
     unsigned off[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) off[n] = (unsigned)((long)(n * 64 + wave * 8 + lr) * ld + cl * 16);
@@ -49,12 +56,13 @@ __global__ void __launch_bounds__(512) feed_kernel(const char* base, long panel_
     f32x4 keep = {0.f, 0.f, 0.f, 0.f};
     f32x4 regs[DEPTH][2];
     auto issue = [&](int t, int slot_reg) {
-        const int koff = (t & 127) * 128 + (t >> 7) * (128 * 16384);      // 128 K-tiles along the rows, then the next 2 MiB slab of the panel
+        const int kt = gm > 0 ? t >> 1 : t;                                // (GEMM-like: A and W half-tiles alternate, same K position)
+        const long koff = (long)(kt % tiles_per_row) * 128 + (long)(kt / tiles_per_row) * (128 * ld) + ((gm > 0 && (t & 1)) ? b_delta : 0);
         char* dst = lds + (t % NS) * 16384 + wave * 8 * 128;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             if (MODE == 0) __builtin_amdgcn_global_load_lds((gptr_t)(pbase + koff + (size_t)off[n]), (lptr_t)(dst + n * 8192), 16, 0, 0);
-            else if (MODE == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + n * 8192), 16, off[n], koff, 0, 0);
+            else if (MODE == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + n * 8192), 16, off[n], (int)koff, 0, 0);
             else regs[slot_reg][n] = *reinterpret_cast<const f32x4*>(pbase + koff + (size_t)off[n]);
         }
     };
@@ -90,7 +98,7 @@ __global__ void __launch_bounds__(512) feed_kernel(const char* base, long panel_
 }
 
 template <int DEPTH, int MODE>
-static float run(const char* base, long panel_stride, int panels_mod, int panel_div, long ld, int ntiles, float* sink, hipStream_t st) {
+static float run(const char* base, long panel_stride, int panels_mod, int panel_div, long ld, int ntiles, float* sink, hipStream_t st, int gm = 0, int gn = 0) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
@@ -98,7 +106,7 @@ static float run(const char* base, long panel_stride, int panels_mod, int panel_
     float best = 1e30f;
     for (int r = 0; r < 4; ++r) {
         CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL((feed_kernel<DEPTH, MODE>), dim3(256), dim3(512), 131072, st, base, panel_stride, panels_mod, panel_div, ld, ntiles, sink);
+        hipLaunchKernelGGL((feed_kernel<DEPTH, MODE>), dim3(256), dim3(512), 131072, st, base, panel_stride, panels_mod, panel_div, ld, ntiles, sink, gm, gn);
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms = 0;
@@ -108,39 +116,52 @@ static float run(const char* base, long panel_stride, int panels_mod, int panel_
     return best;
 }
 
-int main() {
-    const long ld = 16384;                       // row stride in bytes (K = 8192 halves)
+int main(int argc, char** argv) {
     const int ntiles = 1024;                     // half-tiles per block: 16 MiB per block, 4 GiB per launch
-    const long panel_bytes = 128 * ld * (ntiles / 128);      // 16 MiB per panel: 8 slabs of 128 rows x 16 KiB
-    const int npanels = 256;                     // 4 GiB
+    const long panel_bytes = 16l << 20;          // 16 MiB per panel
+    const int npanels = 256 + 16;                // > 4 GiB
     char* buf;
-    CK(hipMalloc(&buf, panel_bytes * npanels + (1 << 20)));
-    CK(hipMemset(buf, 1, panel_bytes * npanels + (1 << 20)));
+    CK(hipMalloc(&buf, panel_bytes * npanels + (64 << 20)));
+    CK(hipMemset(buf, 1, panel_bytes * npanels + (64 << 20)));
     float* sink;
     CK(hipMalloc(&sink, 4096));
     hipStream_t st;
     CK(hipStreamCreate(&st));
-    const char* src_name[3] = {"same", "xcd (4 panels per XCD)", "own (4 GiB)"};
-    const char* mode_name[3] = {"glds", "buffer..lds", "regs + ds_write"};
-    printf("# operand delivery per CU, no arithmetic: 256 blocks x 512 threads, 16 KiB half-tiles, row stride %ld B, %d half-tiles per block\n", ld, ntiles);
-    for (int src = 0; src < 3; ++src) {
-        // blockIdx -> panel: same: 0; xcd: XCD = blockIdx % 8 owns panels 4 xcd .. 4 xcd + 3, chosen by (blockIdx / 8) % 4; own: blockIdx
-        for (int mode = 0; mode < 3; ++mode) {
-            printf("%-24s %-16s", src_name[src], mode_name[mode]);
-            for (int depth = 2; depth <= 8; depth += 2) {
-                int panels_mod = src == 0 ? 1 : (src == 1 ? 32 : 256), panel_div = 1;
-                // (xcd: panel = blockIdx % 32 keeps blockIdx % 8 = XCD constant per panel)
-                float ms = 0;
-#define RUN(D, M) ms = run<D, M>(buf, panel_bytes, panels_mod, panel_div, ld, ntiles, sink, st)
-                if (mode == 0) { if (depth == 2) RUN(2, 0); else if (depth == 4) RUN(4, 0); else if (depth == 6) RUN(6, 0); else RUN(8, 0); }
-                if (mode == 1) { if (depth == 2) RUN(2, 1); else if (depth == 4) RUN(4, 1); else if (depth == 6) RUN(6, 1); else RUN(8, 1); }
-                if (mode == 2) { if (depth == 2) RUN(2, 2); else if (depth == 4) RUN(4, 2); else if (depth == 6) RUN(6, 2); else RUN(8, 2); }
-                const double gbs = 16384.0 * ntiles / (ms * 1e-3) / 1e9;
-                printf("  depth %d: %6.1f GB/s/CU (%5.2f TB/s)", depth, gbs, gbs * 256 / 1e3);
+    printf("# operand delivery per CU, no arithmetic: 256 blocks x 512 threads, 16 KiB half-tiles (128 rows x 128 B), %d half-tiles per block\n", ntiles);
+    if (argc > 1 && argv[1][0] == 'm') {         // part 1: staging mode x depth at the power-of-two row stride
+        const long ld = 16384;
+        const char* src_name[3] = {"same", "xcd (4 panels per XCD)", "own (4 GiB)"};
+        const char* mode_name[3] = {"glds", "buffer..lds", "regs + ds_write"};
+        for (int src = 0; src < 3; ++src)
+            for (int mode = 0; mode < 3; ++mode) {
+                printf("ld %6ld %-24s %-16s", ld, src_name[src], mode_name[mode]);
+                for (int depth = 2; depth <= 8; depth += 2) {
+                    const int panels_mod = src == 0 ? 1 : (src == 1 ? 32 : 256);
+                    float ms = 0;
+#define RUN(D, M) ms = run<D, M>(buf, panel_bytes, panels_mod, 1, ld, ntiles, sink, st)
+                    if (mode == 0) { if (depth == 2) RUN(2, 0); else if (depth == 4) RUN(4, 0); else if (depth == 6) RUN(6, 0); else RUN(8, 0); }
+                    if (mode == 1) { if (depth == 2) RUN(2, 1); else if (depth == 4) RUN(4, 1); else if (depth == 6) RUN(6, 1); else RUN(8, 1); }
+                    if (mode == 2) { if (depth == 2) RUN(2, 2); else if (depth == 4) RUN(4, 2); else if (depth == 6) RUN(6, 2); else RUN(8, 2); }
+                    const double gbs = 16384.0 * ntiles / (ms * 1e-3) / 1e9;
+                    printf("  depth %d: %6.1f GB/s/CU (%5.2f TB/s)", depth, gbs, gbs * 256 / 1e3);
+                }
+                printf("\n");
+                fflush(stdout);
             }
-            printf("\n");
+        return 0;
+    }
+    // part 2: row stride (= K of the GEMM) x sharing pattern, glds, 6 half-tiles in flight
+    const long lds_[] = {1280, 2560, 5120, 10240, 16384, 16384 + 256};
+    struct Src { const char* name; int panels_mod, gm, gn; };
+    const Src srcs[] = {{"same panel everywhere", 1, 0, 0}, {"4 panels per XCD", 32, 0, 0}, {"GEMM 1 x 32 per XCD", 0, 1, 32}, {"GEMM 2 x 16", 0, 2, 16},
+                        {"GEMM 4 x 8", 0, 4, 8}, {"GEMM 8 x 4", 0, 8, 4}, {"own panel (HBM)", 256, 0, 0}};
+    for (long ld : lds_)
+        for (const Src& sc : srcs) {
+            const float ms = run<6, 0>(buf, panel_bytes, sc.panels_mod ? sc.panels_mod : 1, 1, ld, ntiles, sink, st, sc.gm, sc.gn);
+            const double gbs = 16384.0 * ntiles / (ms * 1e-3) / 1e9;
+            printf("row stride %6ld B  %-24s %6.1f GB/s/CU (%5.2f TB/s)  -> a 256 x 256 x 64 tile every %.2f us = %.0f TFLOP/s\n", ld, sc.name, gbs, gbs * 256 / 1e3,
+                   65536.0 / gbs / 1e3, 256.0 * 2 * 256 * 256 * 64 / (65536.0 / gbs / 1e3) / 1e6);
             fflush(stdout);
         }
-    }
     return 0;
 }
