@@ -143,6 +143,8 @@ int lb_conv3x3_narrow_f16(const LbGemmParams* params, void* stream);
 /* Tuning: 1 (default) = persistent blocks (one per CU) whose operand request streams run across tile boundaries;
  * 0 = one (tile, channel block) item per block. */
 void lb_conv_halo_set_persistent(int on);
+/* Tuning: 1 = ping-pong step loop (two wave groups one barrier apart: LDS reads under the partner's MFMAs), 0 = lock-step. */
+void lb_conv_halo_set_pingpong(int on);
 /* Host arithmetic of a halo launch (no device work): kind 0 = not eligible, 3 = 3x3 form, 2 = 2x2 sub-pixel form; the
  * tile width (32 / 16), the number of (tile [, parity], channel block) work items and the grid that walks them. */
 void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long* items, long* grid);
