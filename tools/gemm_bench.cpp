@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     if (set == "b17" || set == "all") shapes.insert(shapes.end(), std::begin(B17), std::end(B17));
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
-    const Variant all_variants[] = {{"auto", 0, 0, 0, 1}, {"pp-m1", 9, 1, 0, 1}, {"pp-g2", 9, 1, 0, 1, 2}, {"pp-g4", 9, 1, 0, 1, 4}, {"pp-g8", 9, 1, 0, 1, 8}, {"pp-r10", 9, 1, 1, 1}, {"pp-d4", 9, 1, 2, 1}, {"pp-sic", 9, 1, 3, 1}, {"pp-m0", 9, 1, 0, 0},
+    const Variant all_variants[] = {{"auto", 0, 0, 0, 1, 8}, {"pp-m1", 9, 1, 0, 1}, {"pp-sk2", 9, 2, 0, 1, 8}, {"pp-sk3", 9, 3, 0, 1, 8}, {"pp-sk4", 9, 4, 0, 1, 8}, {"t4-sk2", 4, 2, 0, 1, 0}, {"pp-g2", 9, 1, 0, 1, 2}, {"pp-g4", 9, 1, 0, 1, 4}, {"pp-g8", 9, 1, 0, 1, 8}, {"pp-r10", 9, 1, 1, 1}, {"pp-d4", 9, 1, 2, 1}, {"pp-sic", 9, 1, 3, 1}, {"pp-m0", 9, 1, 0, 0},
                                     {"w4", 10, 1, 0, 1}, {"t5", 5, 1, 0, 1}, {"t4", 4, 1, 0, 1}, {"t1", 1, 1, 0, 1}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
@@ -123,6 +123,8 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dC, (size_t)s.M * s.N * 2));          // (rocBLAS writes the full M x N also for the GEGLU shapes)
         CK(hipMalloc(&dCref, (size_t)s.M * s.N * 2));
         CK(hipMalloc(&dB, hB.size() * 4));
+        float* dWs;
+        CK(hipMalloc(&dWs, (size_t)lb_gemm_workspace_bytes(s.M, s.N)));
         CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dR, hR.data(), hR.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
@@ -136,7 +138,7 @@ int main(int argc, char** argv) {
             memset(&p, 0, sizeof(p));
             p.A = (const lb_half*)dA; p.W = (const lb_half*)dW[wi]; p.C = out;
             p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldw = s.K; p.ldc = n_out; p.ldr = n_out;
-            p.rows_per_batch = s.M; p.alpha = 1.f; p.zero_page = zero_page;
+            p.rows_per_batch = s.M; p.alpha = 1.f; p.zero_page = zero_page; p.partial = dWs;
             if (s.geglu) p.flags |= LB_GEMM_GEGLU;
             if (s.epi >= 1) p.bias = dB;
             if (s.epi >= 2 && !s.geglu) p.residual = dR;
@@ -209,6 +211,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
         lb_gemm_set_tuning(0, 0);
         for (auto w : dW) CK(hipFree(w));
+        CK(hipFree(dWs));
         CK(hipFree(dA)); CK(hipFree(dR)); CK(hipFree(dC)); CK(hipFree(dCref)); CK(hipFree(dB));
     }
     return 0;
