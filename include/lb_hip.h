@@ -126,10 +126,9 @@ typedef struct LbGemmParams {
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
-void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5, 7 (192x128), 9 (ping-pong 256x256, gemm_pp.hip) or 10 (one wave per SIMD, gemm_w4.hip) and split-K */
+void lb_gemm_set_tuning(int tile, int splitk);   /* testing: force tile 1..5, 7 (192x128) or 9 (ping-pong 256x256, gemm_pp.hip) and split-K */
 void lb_gemm_set_pp_auto(int on);                 /* A/B studies: 0 = the automatic tile policy never picks the ping-pong kernel (default 1) */
 void lb_gemm_pp_set_group(int gm);                /* tuning: tile order of the ping-pong kernel inside an XCD's run: gm block rows down, then the next block column (0 = strip order) */
-void lb_gemm_pp_set_tuning(int ring, int mode);  /* tuning of the ping-pong kernel: ring 0 = 8 slots / 6 half-tiles ahead (default), 1 = 10 slots (160 KiB) / 8 ahead, 2 = 8 slots / 4 ahead (study); mode 1 = one barrier per phase (default), 0 = two */
 void lb_gemm_set_depth(int depth);               /* testing: 1 = one K-tile in flight, 0 = default ring */
 int lb_gemm_plan(const LbGemmParams* p, int* tile, int* splitk, long* blocks); /* the tile (1..5) / split-K / grid lb_gemm_f16 would use; launches nothing */
 /* 3x3 / stride 1 / pad 1 conv from an LDS-resident halo tile; same parameter block as lb_gemm_f16 (conv = 1,
@@ -143,8 +142,6 @@ int lb_conv3x3_narrow_f16(const LbGemmParams* params, void* stream);
 /* Tuning: 1 (default) = persistent blocks (one per CU) whose operand request streams run across tile boundaries;
  * 0 = one (tile, channel block) item per block. */
 void lb_conv_halo_set_persistent(int on);
-/* Tuning: 1 = ping-pong step loop (two wave groups one barrier apart: LDS reads under the partner's MFMAs), 0 = lock-step. */
-void lb_conv_halo_set_pingpong(int on);
 /* Host arithmetic of a halo launch (no device work): kind 0 = not eligible, 3 = 3x3 form, 2 = 2x2 sub-pixel form; the
  * tile width (32 / 16), the number of (tile [, parity], channel block) work items and the grid that walks them. */
 void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long* items, long* grid);

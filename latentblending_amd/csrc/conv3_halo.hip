@@ -68,15 +68,12 @@ template <int KS, int NR, int TAP> constexpr int halo_full_rounds_in_tap() {   /
     return n;
 }
 
-// PP (round 4): PING-PONG form of the step loop.  The eight waves run as two groups of four (waves w and w + 4 share a SIMD)
-// one barrier interval apart; a step is [load segment: this step's requests + all 16 fragment reads | barrier | compute
-// segment: 32 MFMAs | barrier], so while one wave of a SIMD multiplies, its partner reads LDS and issues requests - the
-// lock-step form alternates "everybody reads" with "everybody multiplies" and keeps the matrix pipe ~50 % busy.  Same ring
-// sizes, same request stream, same counted waits (moved: a wave waits for step t+1's operands at the end of step t - the late
-// group at the end of its load segment, the early group after issuing its MFMAs - always before the barrier that precedes
-// the early group's reads of step t+1); every load segment ends with lgkmcnt(0), so a slot's reads have RETURNED before the
-// barrier after which the other group may request into it.  Bit-identical results.
-template <int BN, int TW, int KS = 3, bool PP = false>
+// Round 4: a PING-PONG form of the step loop (two wave groups one barrier apart, a step = load segment | barrier | 32 MFMAs |
+// barrier, as in gemm_pp.hip) was built, verified bit-identical on all shapes and measured 2-13 % SLOWER than this lock-step
+// form on every conv shape of the programs (profiles/r04_halo_pp_ab.txt; git history has the code): the step body below
+// already spreads its requests and its second fragment read between the MFMA groups, and the two waves of a SIMD drift apart
+// on their own.  What a tile pays beyond its MFMA + LDS time is the epilogue and the once-per-chunk activation read.
+template <int BN, int TW, int KS = 3>
 __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p) {
     constexpr int TH = 256 / TW;
     constexpr int NTAP = KS * KS;
@@ -230,20 +227,13 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
 #pragma unroll
         for (int i = 0; i < WI; ++i) issue_weight(i, 0, true, t, t);
 
-    const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);      // PP: 0 = early group (waves 0-3), 1 = late group (waves 4-7)
-    if constexpr (PP) {
-        // step 0's operands: everything but W(1), W(2) (4 loads) has landed; then the late group falls one barrier behind
-        halo_wait_barrier<4>();
-        if (grp == 1) asm volatile("s_barrier" ::: "memory");
-    }
-
     // one step; TAP is a compile-time constant so that every count below is an immediate.  c = chunk within the tile,
     // cc = chunks since the block started (halo buffer / weight slot parity run on across tiles), more = another tile follows
     auto step = [&](auto tap_c, int c, int cc, bool more) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr int P1 = (TAP + NTAP - 1) % NTAP, P2 = (TAP + NTAP - 2) % NTAP;          // taps of the two previous steps
         constexpr int CNT = (2 + halo_full_rounds_in_tap<KS, NR, P1>()) + (2 + halo_full_rounds_in_tap<KS, NR, P2>());
-        if constexpr (!PP) halo_wait_barrier<CNT>();
+        halo_wait_barrier<CNT>();
         const int slot = KS == 3 ? ((cc + TAP) & 3) : TAP;   // (NTAP cc + TAP) mod 4
         const f16* hb = halo0 + (cc & 1) * (HRP * 64);
         const f16* wb = wring + slot * (BN * 64);
@@ -262,30 +252,6 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         const bool w_exists = !wrap || more;
         const int slot3 = (slot + 3) & 3;
         f16x8 a0[TM], w0[TN], a1[TM], w1[TN];
-        if constexpr (PP) {
-            constexpr int CNTN = (2 + halo_full_rounds_in_tap<KS, NR, TAP>()) + (2 + halo_full_rounds_in_tap<KS, NR, P1>());   // all but the loads of this step and the previous one
-            read_frags(hb, wb, shift, 0, a0, w0);
-            read_frags(hb, wb, shift, 1, a1, w1);
-            if constexpr (HaloSched<KS, 0>::tap == TAP) issue_halo(0, hc, hbuf);
-            if constexpr (NR > 2 && HaloSched<KS, 1>::tap == TAP) issue_halo(1, hc, hbuf);
-            if constexpr (NR > 3 && HaloSched<KS, 2>::tap == TAP) issue_halo(2, hc, hbuf);
-            if constexpr (NR > 4 && HaloSched<KS, 3>::tap == TAP) { if (NR - 1 > 3 || wave < EXTRA) issue_halo(3, hc, hbuf); }
-            if constexpr (NR > 4 && HaloSched<KS, 4>::tap == TAP) { if (NR - 1 > 4 || wave < EXTRA) issue_halo(4, hc, hbuf); }
-            if constexpr (NR > 5 && HaloSched<KS, 5>::tap == TAP) { if (wave < EXTRA) issue_halo(5, hc, hbuf); }
-            issue_weight(0, c3, w_exists, TAP3, slot3);
-            issue_weight(1, c3, w_exists, TAP3, slot3);
-            if (grp == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CNTN) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-            mma_rows(a0, w0, 0, TM);
-            mma_rows(a1, w1, 0, TM);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CNTN) : "memory");
-            else asm volatile("s_barrier" ::: "memory");
-            return;
-        }
         read_frags(hb, wb, shift, 0, a0, w0);
         if constexpr (HaloSched<KS, 0>::tap == TAP) issue_halo(0, hc, hbuf);
         if constexpr (NR > 2 && HaloSched<KS, 1>::tap == TAP) issue_halo(1, hc, hbuf);
@@ -358,9 +324,6 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         item = next_item;
         cur = nxt;
     }
-    if constexpr (PP) {
-        if (grp == 0) asm volatile("s_barrier" ::: "memory");       // pairs with the late group's last barrier
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the masked tail requests still target this block's LDS: drain before exit
 }
 
@@ -397,22 +360,15 @@ static void halo_grid(const LbGemmParams& p, int tw, int ks, long& items, long& 
         grid = (long)(halo_num_cus() / period) * period;
 }
 
-// 1 = ping-pong step loop (template parameter PP), 0 = the lock-step form
-static int g_halo_pp = 0;
-extern "C" void lb_conv_halo_set_pingpong(int on) { g_halo_pp = on; }
-
 template <int BN, int TW, int KS = 3>
 static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
     constexpr int TH = 256 / TW;
     constexpr int HRP = (((TH + KS - 1) * (TW + KS - 1) + 7) / 8) * 8;
     constexpr int SMEM = (2 * HRP * 64 + 4 * BN * 64) * (int)sizeof(f16);
     static unsigned long long seen = 0;
-    if (lb_first_call_on_device(seen)) {                // (first call on a device happens at record time, outside any capture)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW, KS, false>),
+    if (lb_first_call_on_device(seen))                  // (first call on a device happens at record time, outside any capture)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW, KS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW, KS, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    }
     static_assert(BN == 128, "halo_grid assumes 128-channel blocks");
     long nblk, grid;
     halo_grid(p, TW, KS, nblk, grid);
@@ -421,8 +377,7 @@ static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
 #ifdef LB_STUDY_BUILD
     pk.reserved_ = g_halo_study;
 #endif
-    if (g_halo_pp) hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS, true>), dim3((unsigned)grid), dim3(512), SMEM, stream, pk);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS, false>), dim3((unsigned)grid), dim3(512), SMEM, stream, pk);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, TW, KS>), dim3((unsigned)grid), dim3(512), SMEM, stream, pk);
     return lb_check_launch(KS == 2 ? "lb_upconv2x_halo_f16" : "lb_conv3x3_halo_f16");
 }
 

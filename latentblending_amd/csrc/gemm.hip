@@ -348,9 +348,6 @@ static bool use_halo(const LbGemmParams& p) {
 // ping-pong 256x256 main loop (gemm_pp.hip): tile code 9
 int lb_gemm_pp_eligible(const LbGemmParams& p);
 int lb_gemm_launch_pp(const LbGemmParams& p, dim3 grid, hipStream_t stream);
-// one-wave-per-SIMD 256x256 main loop (gemm_w4.hip): tile code 10
-int lb_gemm_w4_eligible(const LbGemmParams& p);
-int lb_gemm_launch_w4(const LbGemmParams& p, dim3 grid, hipStream_t stream);
 // direct-to-LDS variant (gemm_glds.hip)
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream);
 void lb_gemm_glds_init();
@@ -391,8 +388,6 @@ static int gemm_launch_impl(LbGemmParams p, int tile, int depth, int variant, in
                             hipStream_t stream) {
     if (tile == 9) {
         lb_gemm_launch_pp(p, grid, stream);
-    } else if (tile == 10) {
-        lb_gemm_launch_w4(p, grid, stream);
     } else if (variant == 1 && p.zero_page != nullptr) {
         lb_gemm_launch_glds(p, tile, stages, grid, stream);
     } else {
@@ -427,7 +422,6 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
     };
     int tile = g_force_tile;
     if (tile == 9 && !lb_gemm_pp_eligible(p)) tile = 0;       // (forced for A/B studies: ineligible problems keep the automatic choice)
-    if (tile == 10 && !lb_gemm_w4_eligible(p)) tile = 0;
     if (!tile) {
         // MI355X sweeps (tools/sweep_gemm.py; profiles/r01_gemm_variant_sweep.txt, r01_gemm_tile4_sweep.txt).
         // Direct-to-LDS family: the 8-wave 256x128 tile with a 3-stage ring (144 KiB, two K-tiles = 96 KiB
@@ -490,7 +484,7 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         if (b64 > 256 && b64 <= 640 && blocks(128, 64) <= 256) tile = 2;
     }
     const int bm = tile == 7 ? 192 : (tile >= 4 ? 256 : (tile == 3 ? 64 : 128));
-    const int bn = (tile == 5 || tile >= 9) ? 256 : ((tile == 1 || tile == 4 || tile == 7) ? 128 : 64);
+    const int bn = (tile == 5 || tile == 9) ? 256 : ((tile == 1 || tile == 4 || tile == 7) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
     // (LN_A: a block must see whole rows of A)

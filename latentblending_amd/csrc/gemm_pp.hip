@@ -1,35 +1,47 @@
-// Ping-pong MFMA GEMM for gfx950: 256 x 256 x 64 block tile, 8 waves in two groups that alternate between a
-// "load" segment (LDS fragment reads + LDS-DMA requests) and a "compute" segment (16 MFMAs) - while one wave of a SIMD
-// multiplies, its partner on the same SIMD feeds itself.  Same contract and epilogues as gemm.hip / gemm_glds.hip (plain
-// and GEGLU GEMMs; lb_gemm_f16 routes here, tile code 9), bit-identical results: every accumulator sees the same K order.
+// Ping-pong MFMA GEMM for gfx950: 256 x 256 x 64 block tile, 8 waves in two groups that alternate between a "load"
+// segment (LDS fragment reads + LDS-DMA requests) and a "compute" segment (16 MFMAs).  Same contract and epilogues as
+// gemm.hip / gemm_glds.hip (plain and GEGLU GEMMs; lb_gemm_f16 routes chip-filling grids here, tile code 9), bit-identical
+// results: every accumulator sees the same K order.
 //
-// Why a third main loop.  The lock-step 8-wave tiles of gemm_glds.hip spend ~1/3 of their wave cycles parked at
-// `vmcnt` + `s_barrier` and keep the matrix pipe ~45-50 % busy (profiles/r02_gemm_pmc.json): all waves read LDS together,
-// then all multiply together, and a two-stage ring of whole 64 KiB K-tiles has at most one K-tile in flight and must be
-// drained at every barrier.  Here
-//   * a K-tile is staged as FOUR half-tiles of 16 KiB, cut so that every half-tile is read in exactly ONE phase of the
-//     K-tile's four phases (by all waves) and is dead afterwards:
+// Why a third main loop.  The lock-step 8-wave tiles of gemm_glds.hip stage whole 64 KiB K-tiles through a two-stage ring:
+// at most one K-tile is in flight and it is drained at every barrier; they spend ~1/3 of their wave cycles parked at
+// `vmcnt` + `s_barrier` (profiles/r02_gemm_pmc.json).  Here
+//   * a K-tile is staged as FOUR half-tiles of 16 KiB, cut so that every half-tile is read in exactly ONE of the K-tile's
+//     four phases (by all waves) and is dead afterwards:
 //         A0 = rows {wr*128 + 0..63}, A1 = rows {wr*128 + 64..127}  (wr = 0, 1: the two wave rows)
 //         B0 = cols {wc*64 + 0..31},  B1 = cols {wc*64 + 32..63}    (wc = 0..3: the four wave columns)
 //     phase 0 multiplies A0 x B0 (reads A0, B0), phase 1 A0 x B1 (reads B1), phase 2 A1 x B1 (reads A1), phase 3 A1 x B0
 //     (reads nothing: B0 stayed in registers) - 24 ds_read_b128 per wave per K-tile, the minimum for a 128 x 64 wave tile;
-//   * the eight 16 KiB slots of the 128 KiB ring are refilled SIX half-tiles ahead of the consumer (a slot is requested
-//     again two phases after its only read), one half-tile per phase, and the only waits are `s_waitcnt vmcnt(8)`: four
-//     half-tiles = 64 KiB stay in flight per CU across every barrier (gemm_glds.hip's 256 x 256 tile: <= 64 KiB issued
-//     and fully drained once per K-tile);
-//   * the two wave groups (wr = 0 / 1: waves w and w + 4 share a SIMD) run one barrier apart, so a SIMD's matrix pipe
-//     sees compute segments back to back while LDS reads, DMA issue and waits hide under the partner's MFMAs.
+//   * half-tile h = 4 t + J (J = 0 A0, 1 B0, 2 B1, 3 A1 of K-tile t) lives in slot h mod 8 of a 128 KiB ring; load segment p
+//     requests half-tile p + 6 (a slot is requested again two phases after its only read), and the only waits are counted:
+//     four half-tiles = 64 KiB (late group: three) stay in flight per CU across every barrier;
+//   * ONE barrier per phase.  Between two barriers the early group (wr = 0) runs [compute phase k, load phase k + 1] while
+//     the late group (wr = 1; waves w and w + 4 share a SIMD) runs [load phase k, compute phase k]: matrix beside memory, then
+//     memory beside matrix; the hand-over in the middle is not a rendezvous - the late group's MFMAs follow the early
+//     group's through the SIMD's matrix pipe.
+//   * tile order inside an XCD's run: GM block rows down, then the next block column, so that the ~32 tiles an XCD works on
+//     at a time form a patch (GM + 32 / GM operand panels through its L2 per K-tile) instead of a 1 x 32 strip (33).
 //
 // Hazards (MI355X: an LDS-DMA is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier the reader
 // has passed; a slot may be re-requested only after every wave's reads of it have RETURNED):
-//   RAW: half-tile h (consumption order A0, B0, B1, A1 per K-tile, consumed in phases 0, 0, 1, 2) is requested in phase
-//        h - 6; every wave waits for its own part in the load segment of the phase BEFORE the consuming one, i.e. one
-//        full barrier interval before the earliest reader (the other group) starts reading.
-//   WAR: the slot of half-tile h held h - 8, read >= 2 phases before the request; the late group's reads of it returned
-//        (its MFMAs consumed them) one barrier interval before the early group issues the request.
+//   RAW: half-tile h is consumed in phase q = h - j + {0, 0, 1, 2}[j].  The early group reads it in interval q - 1 (second
+//        half), the late group in interval q: every wave must have waited for its own part before the barrier that ends
+//        interval q - 2 - the early group in load segment q - 1 (vmcnt(8): it has requested through half-tile q + 5), the
+//        late group in load segment q - 2 (vmcnt(6): through q + 4).
+//   WAR: load segment p requests into the slot of half-tile p - 2, last read in a phase <= p - 2, i.e. in an EARLIER interval
+//        for both groups; reads issued at the end of an interval are waited for by their own wave before it computes.
+//
+// What bounds it (tools/probes/feed_rate.cpp, profiles/r04_feed_rate.txt): with the arithmetic taken away, 256 blocks
+// streaming half-tiles in GEMM-like sharing patterns receive 38 GB/s per CU (1 x 32 strips) to 50 GB/s (4 x 8 / 8 x 4
+// patches) whatever the depth beyond 4 half-tiles, the staging instruction or the row stride - one 256 x 256 x 64 tile every
+// 1.3-1.7 us = 1.26-1.65 PFLOP/s.  This loop runs at 1.3-1.4 PFLOP/s on 8192^3 (the vendor library's stream-K kernels:
+// 1.46-1.51); variants with a deeper ring (10 slots / 8 ahead), a shallower one (4 ahead), two barriers per phase, the
+// requests inside the compute segments, and a one-wave-per-SIMD 4 x (128 x 128) form were built, verified and measured - none
+// beat this one (profiles/r04_gemm_bench_call*.txt, git history).
 //
 // Replaces (third party, reached from /root/reference/latentblending/diffusers_holder.py:336): the torch.nn.Linear
-// layers of the SDXL UNet's transformer blocks at batch >= 8 (q/k/v, attention out, GEGLU, feed-forward out).
+// layers of the SDXL UNet's transformer blocks at batch >= 8 (fused q|k|v, GEGLU, 640-wide feed-forward output) and the
+// per-branch context K|V projection.
 #include "lb_common.h"
 #include "lb_gemm.h"
 
@@ -38,6 +50,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define PP_BK 64
 #define PP_SLOT_H 8192           // halves per half-tile slot: 128 rows x 64 halves = 16 KiB
+#define PP_NS 8                  // ring slots
+#define PP_D 6                   // half-tiles requested ahead of the consumer
+#define PP_LDS_BYTES (PP_NS * PP_SLOT_H * 2)
 
 template <int V> struct PPInt { static constexpr int value = V; };
 typedef PPInt<0> J0; typedef PPInt<1> J1; typedef PPInt<2> J2; typedef PPInt<3> J3;
@@ -45,29 +60,8 @@ typedef PPInt<0> J0; typedef PPInt<1> J1; typedef PPInt<2> J2; typedef PPInt<3> 
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// MODE 0: TWO barriers per phase - load segment | barrier | compute segment | barrier, the second group one barrier late.
-// MODE 1: ONE barrier per phase.  Between two barriers the early group (wr = 0) runs [compute phase k, load phase k + 1]
-//         while the late group (wr = 1) runs [load phase k, compute phase k]: the roles still alternate inside the interval
-//         (matrix beside memory, then memory beside matrix), but the hand-over in the middle is not a rendezvous - the late
-//         group's MFMAs simply follow the early group's through the SIMD's matrix pipe - and only half as many
-//         workgroup-wide synchronisations are paid per K-tile.  The early group reads a half-tile one interval BEFORE the
-//         late group does, so (RAW) the late group waits for its part of a half-tile one phase earlier (one half-tile fewer
-//         may still be in flight at its wait); WAR is unchanged (a slot is requested again by load segment p, its last read
-//         belongs to phase <= p - 2, i.e. to an EARLIER interval for both groups, and the reads issued at the end of an
-//         interval are waited for by their own wave before it computes).
-// NS = ring slots of 16 KiB (8 = 128 KiB, 10 = the whole 160 KiB LDS), D = half-tiles requested ahead of the consumer
-// (<= NS - 2).  Half-tile h = 4 t + J (J = 0 A0, 1 B0, 2 B1, 3 A1 of K-tile t) lives in slot h mod NS; load segment p
-// requests half-tile p + D.  At a wait D - 2 (late group of MODE 1: D - 3) half-tiles stay in flight.
-// SIC (MODE 1 only): the two LDS-DMA requests of a phase are issued INSIDE its compute segment, between the MFMAs (which
-// leave 12 of every 16 issue cycles free), instead of in the load segment - the load segments, whose length decides whether
-// the partner's MFMAs start on time, then hold LDS reads only.  A request issued in compute segment p comes one barrier
-// later than one issued in load segment p, so the ring may run one half-tile further ahead (D <= NS - 1: the slot's last
-// read belongs to phase <= p - 1 and has returned before the barrier that opens the requesting interval).
-template <bool GEGLU, int NS, int D, int MODE, bool SIC = false>
+template <bool GEGLU>
 __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) {
-    static_assert(D >= 4 && D <= NS - 2 + (SIC ? 1 : 0), "a slot is requested again two phases after its only read");
-    static_assert(!SIC || MODE == 1, "requests inside the compute segment: one-barrier form only");
-    constexpr bool PRIO = true;          // s_setprio 1 around the MFMA clusters (measured neutral: profiles/r04_gemm_bench_call2.txt)
     constexpr int BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) f16 lds[];
 
@@ -77,7 +71,7 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     const int wr = wave >> 2, wc = wave & 3;
     const int g = lane >> 4, l16 = lane & 15;
 
-    // ---- block -> tile (XCD-aware bijective remap, then the operand with more bytes is the shared one) ----
+    // ---- block -> tile: XCD-aware bijective remap, then the grouped order (p.reserved_ = GM block rows per group) ----
     const int n_eff = GEGLU ? p.N / 2 : p.N;
     constexpr int BN_OUT = GEGLU ? BN / 2 : BN;
     const int n_blocks = (n_eff + BN_OUT - 1) / BN_OUT;
@@ -88,10 +82,6 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    // Tile order inside an XCD's run.  The ~32 tiles an XCD works on at a time share its 4 MiB L2: as a 1 x 32 strip they
-    // pull 33 operand panels through it per K-tile, as a GM x (32 / GM) patch only GM + 32 / GM (12 for GM = 4).  p.reserved_
-    // = GM > 0: walk GM block rows down, then the next block column ("grouped" order); 0: the strip order of the other
-    // kernels (the operand with more bytes is the shared one).
     int block_m, block_n;
     if (p.reserved_ > 0) {
         const int gm = p.reserved_;
@@ -101,7 +91,7 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         const int in_group = bid - group * per_group;
         block_m = first_m + in_group % rows;
         block_n = in_group / rows;
-    } else {
+    } else {                         // strip order of the other kernels (the operand with more bytes is the shared one)
         const bool w_dominant = n_eff > p.M;
         block_n = w_dominant ? bid / m_blocks : bid % n_blocks;
         block_m = w_dominant ? bid % m_blocks : bid / n_blocks;
@@ -118,10 +108,9 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
 
     // ---- staging: a half-tile = 128 LDS rows of 128 B = two wave instructions per wave (rows n*64 + wave*8 + lr) ----
     // lane (lr = lane >> 3, s = lane & 7) owns physical chunk s of its row and fetches logical chunk s ^ (row & 7).
-    // Per-lane state is ONE 32-bit byte offset per staged row (8 VGPRs); the K position is a scalar added to the uniform
-    // base, so the requests take the `saddr + voffset` form and nothing per-lane changes inside the K loop.  No masking:
-    // rows beyond M / N re-read the last valid row (their accumulator rows / columns are never stored), requests beyond
-    // the K range re-read the last K-tile (staged into slots nobody reads again).
+    // Per-lane state is ONE 32-bit byte offset per staged row; the K position is a scalar added to the uniform base.  No
+    // masking: rows beyond M / N re-read the last valid row (their accumulator rows / columns are never stored), requests
+    // beyond the K range re-read the last K-tile (staged into slots nobody reads again).
     const int lr = lane >> 3;
     const int cl = (lane & 7) ^ (lr & 7);
     unsigned a_off[4];               // [qm * 2 + n]: LDS row n*64 + wave*8 + lr of half-tile A_qm = block row n*128 + qm*64 + wave*8 + lr
@@ -155,7 +144,7 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     const char* const w_base = reinterpret_cast<const char*>(p.W) + (long)kt_begin * (PP_BK * 2);
 
     // ring slot (in halves) of half-tile J of K-tile `tile`
-    auto slot_of = [&](int tile, int J) { return ((4 * tile + J) % NS) * PP_SLOT_H; };
+    auto slot_of = [&](int tile, int J) { return ((4 * tile + J) % PP_NS) * PP_SLOT_H; };
     // request half-tile J (0 = A0, 1 = B0, 2 = B1, 3 = A1) of K-tile `tile` (of this block's range) into its ring slot
     auto stage = [&](auto jc, int tile) {
         constexpr int J = decltype(jc)::value;
@@ -170,19 +159,9 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + n * 64 * PP_BK), 16, 0, 0);
         }
     };
-    auto stage_half = [&](auto jc, int tile, int n) {          // instruction n (0 / 1) of that request
-        constexpr int J = decltype(jc)::value;
-        constexpr bool IS_A = (J == 0 || J == 3);
-        constexpr int Q = (J == 0 || J == 1) ? 0 : 1;
-        const int kt = tile < nkt ? tile : nkt - 1;
-        const long koff = (long)kt * (PP_BK * 2);
-        f16* base = lds + slot_of(tile, J) + (wave * 8) * PP_BK + n * 64 * PP_BK;
-        const char* src = (IS_A ? a_base : w_base) + koff + (size_t)(IS_A ? a_off[Q * 2 + (n & 1)] : w_off[Q * 2 + (n & 1)]);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)base, 16, 0, 0);
-    };
     // load segment of phase (t, I) requests half-tile 4 t + I + D
     auto stage_ahead = [&](auto ic, int t) {
-        constexpr int I = decltype(ic)::value, JJ = (I + D) & 3, DT = (I + D) >> 2;
+        constexpr int I = decltype(ic)::value, JJ = (I + PP_D) & 3, DT = (I + PP_D) >> 2;
         stage(PPInt<JJ>{}, t + DT);
     };
 
@@ -197,7 +176,7 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     }
     f16x8 af[4][2];                  // [i][ks]   rows qm*64 + 16 i of the wave's 128
     f16x8 b0[2][2], b1[2][2];        // [jj][ks]  columns qn*32 + 16 jj of the wave's 64
-    auto read_a = [&](int soff) {        // soff = slot_of(t, J)
+    auto read_a = [&](int soff) {    // soff = slot_of(t, J)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -218,131 +197,89 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // the 16 MFMAs of one phase; with SIC the phase's two requests go between them (after the 4th and the 12th)
-    auto mma = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2], auto ic, int t) {
-        constexpr int QM = decltype(qmc)::value, QN = decltype(qnc)::value, I = decltype(ic)::value;
-        constexpr int JJ = (I + D) & 3, DT = (I + D) >> 2;           // compute segment (t, I) requests half-tile 4 t + I + D
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+    // the 16 MFMAs of one phase (s_setprio 1 around them: the partner wave's load segment never delays an MFMA issue)
+    auto compute = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2]) {
+        constexpr int QM = decltype(qmc)::value, QN = decltype(qnc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
                     acc[QM * 4 + i][QN * 2 + jj] =
                         __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[jj][ks], af[i][ks], acc[QM * 4 + i][QN * 2 + jj], 0, 0, 0);
-                if constexpr (SIC) {
-                    if (i == 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        stage_half(PPInt<JJ>{}, t + DT, ks);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    // ---- prologue: half-tiles 0 .. D-1 ----
-    {
-        auto pro = [&](auto hc) {
-            constexpr int H = decltype(hc)::value;
-            if constexpr (H < D) stage(PPInt<(H & 3)>{}, H >> 2);
-        };
-        pro(PPInt<0>{}); pro(PPInt<1>{}); pro(PPInt<2>{}); pro(PPInt<3>{}); pro(PPInt<4>{}); pro(PPInt<5>{});
-        pro(PPInt<6>{}); pro(PPInt<7>{}); pro(PPInt<8>{}); pro(PPInt<9>{});
-    }
-    pp_wait_vm<2 * (D - 2)>();               // A0 / B0 of K-tile 0 have landed (this wave's part)
+    // ---- prologue: half-tiles 0 .. 5 (K-tile 0 whole, A0 / B0 of K-tile 1) ----
+    stage(J0{}, 0); stage(J1{}, 0); stage(J2{}, 0); stage(J3{}, 0); stage(J0{}, 1); stage(J1{}, 1);
+    pp_wait_vm<2 * (PP_D - 2)>();            // A0 / B0 of K-tile 0 have landed (this wave's part)
     pp_barrier();
 
     // load segments of the four phases of K-tile t (VM = the vmcnt this group waits for, -1 = none)
     auto load0 = [&](int t, auto vm) {       // reads A0, B0
         read_b(slot_of(t, 1), b0);
         read_a(slot_of(t, 0));
-        if constexpr (!SIC) stage_ahead(J0{}, t);
+        stage_ahead(J0{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto load1 = [&](int t, auto vm) {       // reads B1
         read_b(slot_of(t, 2), b1);
-        if constexpr (!SIC) stage_ahead(J1{}, t);
+        stage_ahead(J1{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto load2 = [&](int t, auto vm) {       // reads A1
         read_a(slot_of(t, 3));
-        if constexpr (!SIC) stage_ahead(J2{}, t);
+        stage_ahead(J2{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
     auto load3 = [&](int t, auto vm) {       // reads nothing (B0 stayed in registers)
-        if constexpr (!SIC) stage_ahead(J3{}, t);
+        stage_ahead(J3{}, t);
         if constexpr (decltype(vm)::value >= 0) pp_wait_vm<decltype(vm)::value>();
     };
-    auto compute = [&](auto qmc, auto qnc, const f16x8 (&bf)[2][2], auto ic, int t) {
-        __builtin_amdgcn_sched_barrier(0);
-        mma(qmc, qnc, bf, ic, t);
-        __builtin_amdgcn_sched_barrier(0);
-    };
     typedef PPInt<-1> NOWAIT;
-    constexpr int S = SIC ? 1 : 0;       // (with SIC a load segment comes BEFORE its phase's requests)
-    typedef PPInt<2 * (D - 2 - S)> VM8;  // (names from the D = 6 ring: 8 / 6 requests = 4 / 3 half-tiles in flight at a wait)
-    typedef PPInt<2 * (D - 3 - S)> VM6;
+    typedef PPInt<2 * (PP_D - 2)> VM_EARLY;  // 4 half-tiles stay in flight at the early group's waits
+    typedef PPInt<2 * (PP_D - 3)> VM_LATE;   // 3 at the late group's (it waits one phase earlier)
 
-    if constexpr (MODE == 0) {
-        if (wr == 1) pp_barrier();           // the second group runs one barrier interval behind the first
-        __builtin_amdgcn_sched_barrier(0);
-        for (int t = 0; t < nkt; ++t) {
-            load0(t, VM8{});                 // ... B1 of this K-tile landed
-            pp_barrier();
-            compute(J0{}, J0{}, b0, J0{}, t);
-            pp_barrier();
-            load1(t, VM8{});                 // ... A1 of this K-tile landed
-            pp_barrier();
-            compute(J0{}, J1{}, b1, J1{}, t);
-            pp_barrier();
-            load2(t, NOWAIT{});
-            pp_barrier();
-            compute(J1{}, J1{}, b1, J2{}, t);
-            pp_barrier();
-            load3(t, VM8{});                 // ... A0 / B0 of the next K-tile landed
-            pp_barrier();
-            compute(J1{}, J0{}, b0, J3{}, t);
-            pp_barrier();
-        }
-        if (wr == 0) pp_barrier();           // pairs with the late group's last barrier
-    } else if (wr == 0) {
+    if (wr == 0) {
         // early group: [compute phase k | load phase k + 1] per interval
-        load0(0, VM8{});
+        load0(0, VM_EARLY{});
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nkt; ++t) {
-            compute(J0{}, J0{}, b0, J0{}, t);
-            load1(t, VM8{});
+            compute(J0{}, J0{}, b0);
+            load1(t, VM_EARLY{});            // ... A1 of this K-tile landed
             pp_barrier();
-            compute(J0{}, J1{}, b1, J1{}, t);
+            compute(J0{}, J1{}, b1);
             load2(t, NOWAIT{});
             pp_barrier();
-            compute(J1{}, J1{}, b1, J2{}, t);
-            load3(t, VM8{});
+            compute(J1{}, J1{}, b1);
+            load3(t, VM_EARLY{});            // ... A0 / B0 of the next K-tile landed
             pp_barrier();
-            compute(J1{}, J0{}, b0, J3{}, t);
-            load0(t + 1, VM8{});             // (past the last K-tile: reads of stale slots into dead registers)
+            compute(J1{}, J0{}, b0);
+            load0(t + 1, VM_EARLY{});        // ... B1 of the next K-tile landed (past the last K-tile: reads of stale slots into dead registers)
             pp_barrier();
         }
     } else {
         // late group: [load phase k | compute phase k] per interval; its waits cover what the EARLY group reads in the next interval
-        pp_wait_vm<2 * (D - 3)>();           // B1 of K-tile 0 (the early group reads it in interval 0)
+        pp_wait_vm<2 * (PP_D - 3)>();        // B1 of K-tile 0 (the early group reads it in interval 0)
         pp_barrier();
         __builtin_amdgcn_sched_barrier(0);
         for (int t = 0; t < nkt; ++t) {
-            load0(t, VM6{});                 // ... A1 of this K-tile landed
-            compute(J0{}, J0{}, b0, J0{}, t);
+            load0(t, VM_LATE{});             // ... A1 of this K-tile landed
+            compute(J0{}, J0{}, b0);
             pp_barrier();
             load1(t, NOWAIT{});
-            compute(J0{}, J1{}, b1, J1{}, t);
+            compute(J0{}, J1{}, b1);
             pp_barrier();
-            load2(t, VM6{});                 // ... A0 / B0 of the next K-tile landed
-            compute(J1{}, J1{}, b1, J2{}, t);
+            load2(t, VM_LATE{});             // ... A0 / B0 of the next K-tile landed
+            compute(J1{}, J1{}, b1);
             pp_barrier();
-            load3(t, VM6{});                 // ... B1 of the next K-tile landed
-            compute(J1{}, J0{}, b0, J3{}, t);
+            load3(t, VM_LATE{});             // ... B1 of the next K-tile landed
+            compute(J1{}, J0{}, b0);
             pp_barrier();
         }
     }
@@ -366,39 +303,28 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
     lb_gemm_tile_epilogue<8, 4, GEGLU>(p, acc, m0 + wr * 128 + l16, n0 + wc * 64 + 4 * g, n0 + wc * 32 + 4 * g);
 }
 
-static int g_pp_ring = 0, g_pp_mode = 1;      // ring: 0 = 8 slots / 6 ahead, 1 = 10 slots (160 KiB) / 8 ahead, 2 = 8 slots / 4 ahead (study), 3 = 8 slots / 7 ahead with the requests inside the compute segments
-extern "C" void lb_gemm_pp_set_tuning(int ring, int mode) { g_pp_ring = ring; g_pp_mode = mode; }
+// tile order inside an XCD's run: GM block rows down, then the next block column; 0 = the strip order of the other kernels.
+// 8 measured best of {0, 2, 4, 8} on the B = 17 shapes and the large squares (profiles/r04_gemm_bench_call6.txt)
+static int g_pp_group = 8;
+extern "C" void lb_gemm_pp_set_group(int gm) { g_pp_group = gm; }
 
 int lb_gemm_pp_eligible(const LbGemmParams& p) {
     return !p.conv && p.K % PP_BK == 0 && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_CH_STATS)) && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
            (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);       // 32-bit row offsets
 }
 
-template <bool GEGLU, int NS, int D, int MODE, bool SIC = false>
+template <bool GEGLU>
 static void pp_launch(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
-    constexpr int BYTES = NS * PP_SLOT_H * 2;
     static unsigned long long seen = 0;
     if (lb_first_call_on_device(seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU, NS, D, MODE, SIC>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU, NS, D, MODE, SIC>), grid, dim3(512), BYTES, stream, p);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU>), grid, dim3(512), PP_LDS_BYTES, stream, p);
 }
-
-template <bool GEGLU>
-static void pp_launch_ring(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
-    if (g_pp_mode == 0) return pp_launch<GEGLU, 8, 6, 0>(p, grid, stream);
-    if (g_pp_ring == 1) return pp_launch<GEGLU, 10, 8, 1>(p, grid, stream);
-    if (g_pp_ring == 2) return pp_launch<GEGLU, 8, 4, 1>(p, grid, stream);
-    if (g_pp_ring == 3) return pp_launch<GEGLU, 8, 7, 1, true>(p, grid, stream);
-    return pp_launch<GEGLU, 8, 6, 1>(p, grid, stream);
-}
-
-static int g_pp_group = 8;         // measured best of {0 (strips), 2, 4, 8} on the B = 17 shapes and the large squares (profiles/r04_gemm_bench_call6.txt)
-extern "C" void lb_gemm_pp_set_group(int gm) { g_pp_group = gm; }
 
 int lb_gemm_launch_pp(const LbGemmParams& pin, dim3 grid, hipStream_t stream) {
     LbGemmParams p = pin;
     p.reserved_ = g_pp_group;
-    if (p.flags & LB_GEMM_GEGLU) pp_launch_ring<true>(p, grid, stream);
-    else pp_launch_ring<false>(p, grid, stream);
+    if (p.flags & LB_GEMM_GEGLU) pp_launch<true>(p, grid, stream);
+    else pp_launch<false>(p, grid, stream);
     return 0;
 }

@@ -70,7 +70,6 @@ SIGNATURES = {
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
     "lb_gemm_set_wide_store": (None, [_i]),
-    "lb_gemm_pp_set_tuning": (None, [_i, _i]),
     "lb_gemm_pp_set_group": (None, [_i]),
     "lb_gemm_set_pp_auto": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
@@ -78,7 +77,6 @@ SIGNATURES = {
     "lb_conv3x3_narrow_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_upconv2x_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_conv_halo_set_persistent": (None, [_i]),
-    "lb_conv_halo_set_pingpong": (None, [_i]),
     "lb_conv_halo_plan": (None, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "lb_gemm_plan": (_i, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
@@ -126,7 +124,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_set_pingpong", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_tuning", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 
@@ -174,5 +172,3 @@ if os.environ.get("LB_GEMM_WIDE_STORE"):        # tuning experiments (tools/): 1
     api.lb_gemm_set_wide_store(int(os.environ["LB_GEMM_WIDE_STORE"]))
 if os.environ.get("LB_GEMM_PP_AUTO"):           # A/B studies (tools/): 0 = the tile policy never picks the ping-pong GEMM
     api.lb_gemm_set_pp_auto(int(os.environ["LB_GEMM_PP_AUTO"]))
-if os.environ.get("LB_CONV_HALO_PP"):           # A/B studies (tools/): ping-pong (1) / lock-step (0) step loop of the halo-tile conv kernel
-    api.lb_conv_halo_set_pingpong(int(os.environ["LB_CONV_HALO_PP"]))

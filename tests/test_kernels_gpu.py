@@ -786,12 +786,12 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
 PP_SHAPES = [(4352, 1280, 1280), (512, 768, 640), (300, 260, 128), (1000, 3840, 64), (256, 256, 192), (4352, 512, 5120)]
 
 
-@pytest.mark.parametrize("ring,mode", [(0, 1), (1, 1), (2, 1), (3, 1), (0, 0)])
+@pytest.mark.parametrize("group", [8, 0, 3])
 @pytest.mark.parametrize("shape", PP_SHAPES)
-def test_gemm_pingpong(shape, ring, mode, results_log):
+def test_gemm_pingpong(shape, group, results_log):
     """gemm_pp.hip against the fp32 reference AND bit for bit against the lock-step tiles (same K order per accumulator);
-    ring 0 = 8 slots / 6 half-tiles ahead, 1 = 10 slots (the whole 160 KiB LDS) / 8 ahead, 2 = 8 slots / 4 ahead, 3 = 8 slots / 7 ahead with the requests issued inside the compute segments; mode 1 = one barrier
-    per phase (default), 0 = two; ragged M / N (rows beyond the edge re-read the last valid row), K = 64 (one K-tile: prologue + drain only), an odd number of K-tiles,
+    group = tile order inside an XCD's run (8 block rows per group = the default, 0 = strips, 3 = a width that does not divide the
+    block rows); ragged M / N (rows beyond the edge re-read the last valid row), K = 64 (one K-tile: prologue + drain only), an odd number of K-tiles,
     bias / residual epilogue.  Repeated launches: a staging race would show as run-to-run differences."""
     o, l = ops(), lib()
     M, N, K = shape
@@ -803,12 +803,12 @@ def test_gemm_pingpong(shape, ring, mode, results_log):
     try:
         lock_step = o.gemm(Ad, Wd, bias=bd, residual=rd)
         l.api.lb_gemm_set_tuning(9, 1)
-        l.api.lb_gemm_pp_set_tuning(ring, mode)
+        l.api.lb_gemm_pp_set_group(group)
         runs = [o.gemm(Ad, Wd, bias=bd, residual=rd) for _ in range(6)]
     finally:
         l.api.lb_gemm_set_tuning(0, 0)
-        l.api.lb_gemm_pp_set_tuning(0, 1)
-    check_close(results_log, f"pp_gemm_{M}x{N}x{K}_ring{ring}_mode{mode}", runs[0], ref)
+        l.api.lb_gemm_pp_set_group(8)
+    check_close(results_log, f"pp_gemm_{M}x{N}x{K}_group{group}", runs[0], ref)
     assert torch.equal(runs[0], lock_step)
     for r in runs[1:]:
         assert torch.equal(r, runs[0])
@@ -832,58 +832,5 @@ def test_gemm_pingpong_geglu_and_splitk(results_log):
         A, W = rnd(512, 1280, seed=98), rnd(768, 1280, seed=99, scale=1280 ** -0.5)
         got = o.gemm(A.to(DEV), W.to(DEV))
         check_close(results_log, "pp_splitk3", got, A.float() @ W.float().t())
-    finally:
-        l.api.lb_gemm_set_tuning(0, 0)
-
-
-# ------------------------------------------------------------------ one-wave-per-SIMD 256x256 GEMM (gemm_w4.hip, tile code 10)
-@pytest.mark.parametrize("shape", PP_SHAPES + [(8192, 512, 1280)])
-def test_gemm_w4(shape, results_log):
-    """gemm_w4.hip (4 waves x 128x128, accumulators under fixed AGPR names, software-pipelined K loop) against the fp32
-    reference and bit for bit against the lock-step tiles; ragged M / N, one K-tile, odd K-tile counts; repeated launches."""
-    o, l = ops(), lib()
-    M, N, K = shape
-    A, W = rnd(M, K, seed=101), rnd(N, K, seed=102, scale=K ** -0.5)
-    bias, res = rnd(N, seed=103, dtype=torch.float32), rnd(M, N, seed=104)
-    ref = A.float() @ W.float().t() + bias + res.float()
-    Ad, Wd, bd, rd = A.to(DEV), W.to(DEV), bias.to(DEV), res.to(DEV)
-    l.api.lb_gemm_set_tuning(1, 1)
-    try:
-        lock_step = o.gemm(Ad, Wd, bias=bd, residual=rd)
-        l.api.lb_gemm_set_tuning(10, 1)
-        runs = [o.gemm(Ad, Wd, bias=bd, residual=rd) for _ in range(6)]
-    finally:
-        l.api.lb_gemm_set_tuning(0, 0)
-    check_close(results_log, f"w4_gemm_{M}x{N}x{K}", runs[0], ref)
-    assert torch.equal(runs[0], lock_step)
-    for r in runs[1:]:
-        assert torch.equal(r, runs[0])
-
-
-def test_gemm_w4_geglu_epilogues_and_splitk(results_log):
-    o, l = ops(), lib()
-    l.api.lb_gemm_set_tuning(10, 1)
-    try:
-        for (M, C, mult) in [(4352, 1280, 8), (300, 640, 8), (520, 320, 2)]:
-            A, W = rnd(M, C, seed=105), rnd(mult * C, C, seed=106, scale=C ** -0.5)
-            bias = rnd(mult * C, seed=107, dtype=torch.float32, scale=0.1)
-            h, gate = (A.float() @ W.float().t() + bias).chunk(2, dim=-1)
-            got = o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_GEGLU)
-            assert got.shape == (M, mult * C // 2)
-            check_close(results_log, f"w4_geglu_{M}x{C}x{mult}", got, h * F.gelu(gate))
-            l.api.lb_gemm_set_tuning(1, 1)
-            assert torch.equal(o.gemm(A.to(DEV), W.to(DEV), bias=bias.to(DEV), flags=l.GEMM_GEGLU), got)
-            l.api.lb_gemm_set_tuning(10, 1)
-        # fp32 output + SiLU + per-sample row vector (time-embedding add): the epilogue runs per 16-row fragment row here
-        M, N, K = 1024, 640, 320
-        A, W = rnd(M, K, seed=108), rnd(N, K, seed=109, scale=K ** -0.5)
-        rv = rnd(4, N, seed=110)
-        ref = A.float() @ W.float().t() + rv.float().repeat_interleave(256, dim=0)
-        got = o.gemm(A.to(DEV), W.to(DEV), rowvec=rv.to(DEV), rows_per_batch=256, flags=l.GEMM_OUT_F32 | l.GEMM_SILU)
-        check_close(results_log, "w4_rowvec_silu_f32", got, F.silu(ref))
-        l.api.lb_gemm_set_tuning(10, 3)                      # split-K slabs (uneven slices: 20 K-tiles / 3)
-        A, W = rnd(512, 1280, seed=111), rnd(768, 1280, seed=112, scale=1280 ** -0.5)
-        got = o.gemm(A.to(DEV), W.to(DEV))
-        check_close(results_log, "w4_splitk3", got, A.float() @ W.float().t())
     finally:
         l.api.lb_gemm_set_tuning(0, 0)

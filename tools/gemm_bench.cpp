@@ -68,7 +68,7 @@ static void fill_half(std::vector<__half>& v, float scale) {
     for (auto& x : v) x = __float2half(frand() * scale);
 }
 
-struct Variant { const char* name; int tile; int splitk; int ring; int mode; int group = 0; };
+struct Variant { const char* name; int tile; int splitk; int group; };
 
 int main(int argc, char** argv) {
     const std::string set = argc > 1 ? argv[1] : "b17";
@@ -77,8 +77,7 @@ int main(int argc, char** argv) {
     if (set == "b17" || set == "all") shapes.insert(shapes.end(), std::begin(B17), std::end(B17));
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
-    const Variant all_variants[] = {{"auto", 0, 0, 0, 1, 8}, {"pp-m1", 9, 1, 0, 1}, {"pp-sk2", 9, 2, 0, 1, 8}, {"pp-sk3", 9, 3, 0, 1, 8}, {"pp-sk4", 9, 4, 0, 1, 8}, {"t4-sk2", 4, 2, 0, 1, 0}, {"pp-g2", 9, 1, 0, 1, 2}, {"pp-g4", 9, 1, 0, 1, 4}, {"pp-g8", 9, 1, 0, 1, 8}, {"pp-r10", 9, 1, 1, 1}, {"pp-d4", 9, 1, 2, 1}, {"pp-sic", 9, 1, 3, 1}, {"pp-m0", 9, 1, 0, 0},
-                                    {"w4", 10, 1, 0, 1}, {"t5", 5, 1, 0, 1}, {"t4", 4, 1, 0, 1}, {"t1", 1, 1, 0, 1}};
+    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t1", 1, 1, 8}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
     {
@@ -146,7 +145,6 @@ int main(int argc, char** argv) {
         };
         auto run = [&](const Variant& v, int wi, __half* out) {
             lb_gemm_set_tuning(v.tile, v.splitk);
-            lb_gemm_pp_set_tuning(v.ring, v.mode);
             lb_gemm_pp_set_group(v.group);
             LbGemmParams p = params(wi, out);
             const int rc = lb_gemm_f16(&p, stream);

@@ -1,4 +1,4 @@
-"""Audit of gemm_w4.hip's code object (run here, no GPU): the kernel keeps its 64 accumulator tiles in a[0:255] under fixed
+"""Audit of tools/probes/gemm_w4.hip's code object (run here, no GPU): the kernel keeps its 64 accumulator tiles in a[0:255] under fixed
 names behind the compiler's back, so the compiler must never touch the accumulator file itself and must never spill.
 Checks the hipcc assembly of every instantiation: no v_accvgpr_* outside ;;#ASMSTART / ;;#ASMEND, no scratch access,
 exactly 128 in-place MFMAs per K-tile iteration of the main loop.   Usage: python tools/probes/check_w4_asm.py"""
@@ -10,12 +10,13 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(ROOT, "latentblending_amd", "csrc")
+PROBE = os.path.join(ROOT, "tools", "probes", "gemm_w4.hip")
 
 
 def main():
     with tempfile.TemporaryDirectory() as td:
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-I", SRC, "-S", "--cuda-device-only",
-               os.path.join(SRC, "gemm_w4.hip"), "-o", os.path.join(td, "w4.s")]
+               PROBE, "-o", os.path.join(td, "w4.s")]
         subprocess.check_call(cmd)
         text = open(os.path.join(td, "w4.s")).read()
     kernels = re.findall(r"^(_Z18gemm_f16_w4_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)

@@ -1,3 +1,9 @@
+// PROBE (round 4, not part of liblbhip.so): built as tile code 10 at commit "gemm_w4.hip: one-wave-per-SIMD ...", verified
+// bit-identical to the shipped kernels on every shape, measured 0.94-1.05 PFLOP/s on the large squares and 0.24-0.86 on the
+// B = 17 shapes (profiles/r04_gemm_bench_call3.txt: below the ping-pong kernel everywhere - its requests are only one K-tile
+// deep, and 30 % of its wave cycles are waits for them), then taken out of the library.  Kept here for the technique: 256
+// accumulators under fixed AGPR names behind inline-asm MFMAs (hipcc's own allocation of 256 loop-carried accumulators
+// rotates them through VGPRs and 1 KiB of scratch per lane), audited by tools/probes/check_w4_asm.py.
 // One-wave-per-SIMD MFMA GEMM for gfx950: 256 x 256 x 64 block tile, FOUR waves (2 x 2), each owning a 128 x 128 output tile
 // (256 fp32 accumulator registers per lane - the whole accumulator half of the 512-entry register file), the K loop
 // software-pipelined INSIDE every wave's instruction stream: while the 64 MFMAs of one 32-deep k-step execute, the same wave
