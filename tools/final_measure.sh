@@ -5,7 +5,8 @@
 #   3. tools/pmc_summary.py folds them into profiles/<tag>_rocprof_summary.json  (bench.py reads roofline.traffic from it)
 #   4. the bench line itself, cfg 2 (+ the secondary lines: skewed metric, cfg 3)
 # Raw traces are dropped after summarising (gpurun merges at most 64 MiB back).
-TAG=${1:-r03}
+TAG=${1:-r04}
+COMMIT=${2:-unknown}        # git rev-parse --short HEAD of the tree being measured (passed in: the GPU box has no .git)
 R=$PWD
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -20,7 +21,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $C rc=$?"
 done
 cd $R
-python tools/pmc_summary.py $TAG gpurun_out "$ARGS (kernel stats) / $PARGS (PMC passes)" > $OUT/${TAG}_pmc_summary.log 2>&1
+python tools/pmc_summary.py $TAG gpurun_out "$ARGS (kernel stats) / $PARGS (PMC passes)" $COMMIT > $OUT/${TAG}_pmc_summary.log 2>&1
 cp profiles/${TAG}_rocprof_summary.json $OUT/ 2>/dev/null
 # keep the per-kernel summaries, drop the raw traces
 for f in $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" -o -name "*domain_stats.csv"); do cp $f $OUT/${TAG}_bench_$(basename $f | sed 's/^[0-9]*_//'); done

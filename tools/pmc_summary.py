@@ -10,6 +10,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"      # directory holding <tag>_stats/, <tag>_pmc_FETCH_SIZE/, <tag>_pmc_WRITE_SIZE/
 bench_args = sys.argv[3] if len(sys.argv) > 3 else "--steps 20 --warmup 5"
+commit = sys.argv[4] if len(sys.argv) > 4 else "not recorded"     # the commit the measured tree was built from (the GPU box has no .git)
 
 
 def family(name):
@@ -23,7 +24,7 @@ def family(name):
     return "other"
 
 
-out = {}
+out = {"commit": commit}
 stats = glob.glob(f"{src}/{tag}_stats/**/*kernel_stats.csv", recursive=True) or glob.glob(f"{src}/{tag}_stats/*kernel_stats.csv")
 if stats:
     fam = collections.defaultdict(lambda: [0.0, 0])
@@ -57,6 +58,6 @@ if len(pmc) == 2:
                                       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
                                               f"`bench.py {bench_args} --no-graphs --no-cpu-baseline --no-roofline --no-secondary`; FETCH x2 correction "
                                               "(MI355X_MICROARCH.md §HBM); Infinity-Cache hits are counted; GEMM family = "
-                                              "gemm_f16_* + conv3x3_halo_kernel launches"}
+                                              "gemm_f16_* (ping-pong, direct-to-LDS, register-ring) + conv3x3_halo_kernel + conv3x3_narrow_kernel launches"}
 json.dump(out, open(f"profiles/{tag}_rocprof_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
