@@ -522,6 +522,17 @@ def secondary_lines(pipe, args, branches):
         dr = be.stats.get("speculation_dropped", 0) / 3
         out.append({"name": "cfg2 under a skewed metric (x exp(3 x position))", "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                     "frontier_rounds": be.stats.get("frontier_rounds", 0) / 3, "speculation_hit_rate": (ev - dr) / ev if ev else None})
+        # the same two metrics under TWO-STAGE speculation (BlendingEngine.two_stage_speculation: 7 branches with the anchors, then
+        # 8 chosen from known distances): two rounds whatever the metric - the robust setting for real checkpoints
+        for skew in (3.0, 0.0):
+            be.two_stage_speculation = True
+            be.pair_metric = skewed_metric(be, skew) if skew else None
+            n, dt = timed(be, 3, 1)
+            ev = be.stats.get("speculation_evaluated", 0) / 3
+            dr = be.stats.get("speculation_dropped", 0) / 3
+            out.append({"name": "cfg2, two-stage speculation, " + ("skewed metric (x exp(3 x position))" if skew else "the benchmark's own metric"),
+                        "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "frontier_rounds": be.stats.get("frontier_rounds", 0) / 3,
+                        "speculation_hit_rate": (ev - dr) / ev if ev else None})
     except Exception as exc:
         out.append({"name": "cfg2 under a skewed metric", "error": repr(exc)})
     try:    # opt-in engine feature, NOT the metric: the reference performs these forwards, so the headline does too

@@ -76,6 +76,12 @@ class BlendingEngine:
         self.pair_metric = None             # optional callable(frame_a, frame_b, fract_a, fract_b) -> distance replacing the
         #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
+        self.two_stage_speculation = False  # fused first round (single-level trees): False = ALL stems at once in level order - one
+        #                                     round when the metric is balanced, several small latency-bound rounds and dropped
+        #                                     branches when it is not; True = only the complete top levels of the binary splitting
+        #                                     that fit HALF the stems (7 of 15) share the anchors' batches, the second round picks the
+        #                                     rest best-first from the 8 gap distances then KNOWN: two rounds whatever the metric
+        #                                     (tree identical either way: a gap's child does not depend on the order of evaluation)
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
         self.fuse_recycled_anchor = True    # ... also when an anchor is recycled (swap_forward chains, precomputed key frames): the
         #                                     fused wavefront takes the stored trajectory as given and denoises only the other one
@@ -577,7 +583,13 @@ class BlendingEngine:
         pipe, steps = self.dh.pipe, self.num_inference_steps
         idx_injection, stems = int(self.list_idx_injection[0]), int(self.list_nmb_stems[0])
         self.dh.set_num_inference_steps(steps)
-        gaps = self._bfs_midpoints(min(self.frontier_width, stems))
+        width = min(self.frontier_width, stems)
+        if self.two_stage_speculation:
+            w = 1
+            while 2 * w + 1 <= (stems + 1) // 2:
+                w = 2 * w + 1               # complete levels of the binary splitting: 1, 3, 7, 15, ...
+            width = min(width, w)
+        gaps = self._bfs_midpoints(width)
         coeffs = planner.parental_crossfeed_coeffs(steps, idx_injection, self.parental_crossfeed_power,
                                                    self.parental_crossfeed_range, self.parental_crossfeed_decay)
         guid = [planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper, m) for _, _, m in gaps]

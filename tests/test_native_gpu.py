@@ -331,6 +331,50 @@ def test_frontier_equals_sequential(results_log):
     assert d.mean() <= 1.0
 
 
+@pytest.mark.parametrize("skew", [0.0, 3.0])
+def test_two_stage_speculation_commits_the_sequential_tree(skew, results_log):
+    """BlendingEngine.two_stage_speculation on the fused wavefront (single-level tree, deterministic Euler so that the order of
+    evaluation cannot change a sample): the complete top levels that fit half the stems go with the anchors, the rest is chosen
+    best-first from the distances then known - same tree as the sequential greedy loop and as the all-at-once speculation,
+    under the pipe's own metric and under a metric skewed by exp(3 x position), in exactly two rounds."""
+    import math
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    set_backend(None)
+    _, p, tape = make_pair(turbo=False)
+
+    def run(width, two_stage):
+        np.random.seed(0)
+        be = BlendingEngine(p, verbose=False, frontier_width=width, do_compile=True)
+        be.two_stage_speculation = two_stage
+        be.set_dimensions((128, 128))
+        be.set_num_inference_steps(6)
+        be.set_guidance_scale(3.0)
+        be.list_idx_injection, be.list_nmb_stems = [3], [15]          # one level, 15 stems: the cfg-2 tree shape on the base sampler
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        if skew:
+            def similarity(a, b, fa, fb):
+                d = p.native_frame_distances([(a, b)])[0]
+                return d * math.exp(skew * 0.5 * ((0.5 if fa is None else fa) + (0.5 if fb is None else fb)))
+            be.pair_metric = similarity
+        tape.reset()
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+        return be, [np.asarray(i).astype(np.int32) for i in imgs]
+    seq, f_seq = run(1, False)
+    allin, f_all = run(16, False)
+    two, f_two = run(16, True)
+    assert seq.tree_fracts == allin.tree_fracts == two.tree_fracts and len(two.tree_fracts) == 17
+    assert two.stats["frontier_rounds"] == 2 and two.stats["speculation_evaluated"] - two.stats.get("speculation_dropped", 0) == 15
+    d = np.stack([np.abs(a - b) for a, b in zip(f_two, f_seq)])
+    results_log[f"two_stage_speculation_skew{skew}"] = {"rounds_two_stage": two.stats["frontier_rounds"], "rounds_all_at_once": allin.stats["frontier_rounds"],
+                                                        "evaluated_two_stage": two.stats["speculation_evaluated"],
+                                                        "evaluated_all_at_once": allin.stats["speculation_evaluated"], "mean_abs_u8": float(d.mean())}
+    assert d.mean() <= 1.0
+    if skew:
+        assert seq.tree_fracts != [k / 16 for k in range(17)]      # (the skew really bends the tree)
+
+
 @pytest.mark.slow
 def test_full_size_sdxl_unet_and_vae(results_log):
     """BASELINE shapes: full SDXL UNet (2.57 B params) at B=1, 64x64 latent (512^2) and the full VAE
