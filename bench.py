@@ -373,7 +373,7 @@ def cpu_baseline(unet_w, vae_w, census):
         has): the thread count that is fastest here is the one everything below uses, and every timing is in the line;
     (1) the metric's workload (cfg 2) - 38 UNet forwards, 17 decodes, the LPIPS policy, 17 frames - really RUN once end to end
         through the engine's host layer on the oracle pipe when the timed samples predict <= LB_CPU_BASELINE_BUDGET seconds
-        (default 90), otherwise extrapolated from the samples x the transition census (the line says which);
+        (default 180), otherwise extrapolated from the samples x the transition census (the line says which);
     (2) BASELINE.md section 4's cfg-1-scale tree (SDXL-Turbo 256^2, the smallest valid tree), also run."""
     import contextlib
     import io
@@ -421,7 +421,7 @@ def cpu_baseline(unet_w, vae_w, census):
                f"{n_sl:.0f} slerp -> {t_transition:.1f} s predicted")
     out = {"value": n_vae / t_transition, "unit": "frames/s", "cores": cores, "kind": "port", "host": host,
            "measured": False, "sample": samples + " (EXTRAPOLATED: the prediction exceeds the budget for a real run)"}
-    budget = float(os.environ.get("LB_CPU_BASELINE_BUDGET", "90"))
+    budget = float(os.environ.get("LB_CPU_BASELINE_BUDGET", "180"))
 
     def oracle_engine(size, steps, depth, branches):
         o = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=ucfg, vae_cfg=vcfg, weights=unet_w, vae_weights=vae_w)

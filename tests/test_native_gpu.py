@@ -234,7 +234,7 @@ def test_recycled_anchor_goes_through_the_fused_wavefront(results_log):
     """swap_forward + run_transition(recycle_img1=True) in frontier mode: the fused wavefront takes the recycled anchor's stored
     trajectory as given (known_anchors) and denoises only the new one - small batches of 1, large ones of 1 + G.  Against the
     unfused path on the same pipe (same noise tape: same draws in the same order) the trees are equal and the frames differ
-    only by batch-composition rounding; against the sequential oracle engine they are within the model tolerance."""
+    only by batch-composition rounding; against the oracle pipe under the same frontier they are within the model tolerance."""
     from latentblending_amd import BlendingEngine
     from latentblending_amd.backend import set_backend
     o, p, tape = make_pair(turbo=True)
@@ -242,8 +242,9 @@ def test_recycled_anchor_goes_through_the_fused_wavefront(results_log):
     for name in ("oracle", "unfused", "fused"):
         set_backend(R.TorchCpuBackend() if name == "oracle" else None)
         np.random.seed(0)
-        if name == "oracle":
-            be = BlendingEngine(o, metric=R.OracleLPIPS(7), verbose=False)
+        if name == "oracle":    # (the same speculative frontier on the oracle pipe: an ancestral sampler's noise tape is consumed in
+            #                      EVALUATION order, so only engines that evaluate in the same order give every branch the same noise)
+            be = BlendingEngine(o, metric=R.OracleLPIPS(7), verbose=False, frontier_width=4)
         else:
             be = BlendingEngine(p, verbose=False, frontier_width=4)
             be.fuse_recycled_anchor = name == "fused"
