@@ -38,6 +38,10 @@
 // 1.46-1.51); variants with a deeper ring (10 slots / 8 ahead), a shallower one (4 ahead), two barriers per phase, the
 // requests inside the compute segments, and a one-wave-per-SIMD 4 x (128 x 128) form were built, verified and measured - none
 // beat this one (profiles/r04_gemm_bench_call*.txt, git history).
+// LayerNorm folding (LB_GEMM_LN_A) is NOT offered here: two forms were built and verified (row statistics by v_dot2 on the A
+// fragments inside the compute segments; and split over the four wave columns, inside the load segments) and cost the
+// loop +40 % / +19 % on the GEGLU projection and +28 % / +17 % on q|k|v - more than the 8.7 us LayerNorm launch they
+// replace (profiles/r04_ln_pp_ab.txt): v_dot2 does not hide beside the MFMAs of either wave of a SIMD.
 //
 // Replaces (third party, reached from /root/reference/latentblending/diffusers_holder.py:336): the torch.nn.Linear
 // layers of the SDXL UNet's transformer blocks at batch >= 8 (fused q|k|v, GEGLU, 640-wide feed-forward output) and the

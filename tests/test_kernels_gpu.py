@@ -426,9 +426,12 @@ def test_gemm_layernorm_fused(case, tile, results_log):
     try:
         got = o.gemm(x.to(DEV), wf.to(DEV), bias=b2.to(DEV), flags=l.GEMM_GEGLU if geglu else 0,
                      ln=(colsum.to(DEV), 1e-5))
+        again = o.gemm(x.to(DEV), wf.to(DEV), bias=b2.to(DEV), flags=l.GEMM_GEGLU if geglu else 0,
+                       ln=(colsum.to(DEV), 1e-5))
     finally:
         l.api.lb_gemm_set_tuning(0, 0)
     check_close(results_log, f"gemm_ln_fused_{'_'.join(map(str, case))}_tile{tile}", got, ref, rel=3e-3, frac=2 ** -7)
+    assert torch.equal(got, again)
 
 
 # ------------------------------------------------------------------ attention ----------------
