@@ -82,7 +82,7 @@ enum {
                               * there): besides C, write per (64-pixel row block, output channel) the (sum, sum of squares) of
                               * the STORED values to ch_stats[channel][row block] (float2, channel-major) - the GroupNorm statistics of this conv's
                               * output without a second pass over it (lb_groupnorm_from_stats).  Row block = (tile [, parity])
-                              * * 4 + wave row: lb_conv_halo_plan reports items; rows per sample = items / channel blocks / B * 4 */
+                              * * 4 + wave row; rows per sample: lb_gemm_ch_stat_rows) */
     LB_GEMM_LN_A = 64        /* A is consumed through a LayerNorm over its K columns (K = the normalised width):
                                 C = LN(A) . Wt computed as rstd_m * (A . W'^T - mean_m * colsum) + bias with
                                 W' = W * gamma (folded by the caller), ln_colsum[n] = sum_k W'[n][k],
@@ -122,6 +122,8 @@ typedef struct LbGemmParams {
     float ln_eps;            /* LB_GEMM_LN_A: LayerNorm epsilon */
     int reserved2_;
     float* ch_stats;         /* LB_GEMM_CH_STATS: output [N][row blocks] float2 (sum, sum of squares), else unused */
+    int ch_stats_rows;       /* LB_GEMM_CH_STATS: row blocks per channel the caller's buffer holds = B * lb_gemm_ch_stat_rows();
+                              * the launcher refuses any other value (the kernel's layout and the buffer cannot drift apart) */
 } LbGemmParams;
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
@@ -145,6 +147,10 @@ void lb_conv_halo_set_persistent(int on);
 /* Host arithmetic of a halo launch (no device work): kind 0 = not eligible, 3 = 3x3 form, 2 = 2x2 sub-pixel form; the
  * tile width (32 / 16), the number of (tile [, parity], channel block) work items and the grid that walks them. */
 void lb_conv_halo_plan(const LbGemmParams* params, int* kind, int* tile_w, long* items, long* grid);
+/* LB_GEMM_CH_STATS: row blocks PER SAMPLE of the statistics buffer ([N][B * rows] float2) the launch lb_gemm_f16 would make
+ * for these parameters writes - from the same routing and the same tile constants as the launch itself; 0 = this problem does
+ * not run on a halo-tile kernel (no statistics: the consumer runs the two-pass GroupNorm).  Launches nothing. */
+int lb_gemm_ch_stat_rows(const LbGemmParams* params);
 /* "nearest-2x upsample, then 3x3 conv" (UNet / VAE upsamplers) as ONE launch of the halo-tile kernel in its 2x2 sub-pixel
  * form: conv = 1, scatter = 2, KH = KW = 2, W = [4][N][4*Cin] stacked pre-summed kernels, C = [B][2H][2W][ldc]. */
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);

@@ -360,6 +360,20 @@ static void halo_grid(const LbGemmParams& p, int tw, int ks, long& items, long& 
         grid = (long)(halo_num_cus() / period) * period;
 }
 
+// LB_GEMM_CH_STATS: row blocks of the whole launch = (items / channel blocks) * 4 wave rows - the host twin of `stat_rows` in
+// the kernel's epilogue (0 = not a halo launch)
+int lb_upconv_halo_eligible(const LbGemmParams& p);
+int lb_conv3x3_halo_eligible(const LbGemmParams& p);
+long lb_conv_halo_stat_rows_total(const LbGemmParams& p) {
+    int tw = 0, ks = 0;
+    if ((tw = lb_upconv_halo_eligible(p)) != 0) ks = 2;
+    else if ((tw = lb_conv3x3_halo_eligible(p)) != 0) ks = 3;
+    if (!ks) return 0;
+    long items, grid;
+    halo_grid(p, tw, ks, items, grid);
+    return items / ((p.N + 127) / 128) * 4;
+}
+
 template <int BN, int TW, int KS = 3>
 static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
     constexpr int TH = 256 / TW;
@@ -393,7 +407,8 @@ int lb_upconv_halo_eligible(const LbGemmParams& p) {
 }
 
 int lb_upconv_halo_launch(LbGemmParams p, hipStream_t stream) {
-    LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS) || p.ch_stats != nullptr, "halo upconv: LB_GEMM_CH_STATS needs ch_stats");
+    LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS) || (p.ch_stats != nullptr && p.ch_stats_rows == lb_conv_halo_stat_rows_total(p)),
+               "halo upconv: LB_GEMM_CH_STATS needs ch_stats with ch_stats_rows = B * lb_gemm_ch_stat_rows()");
     if (p.alpha == 0.f) p.alpha = 1.f;
     p.splitk = 1;
     return lb_upconv_halo_eligible(p) == 32 ? launch_halo<128, 32, 2>(p, stream) : launch_halo<128, 16, 2>(p, stream);
@@ -428,6 +443,8 @@ long lb_conv3x3_halo_blocks(const LbGemmParams& p) {
 int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream) {
     LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS) || (p.ch_stats != nullptr && !(p.flags & LB_GEMM_TRANS_OUT)),
                "halo conv: LB_GEMM_CH_STATS needs ch_stats and a row-major output");
+    LB_REQUIRE(!(p.flags & LB_GEMM_CH_STATS) || p.ch_stats_rows == lb_conv_halo_stat_rows_total(p),
+               "halo conv: ch_stats_rows must be B * lb_gemm_ch_stat_rows() (the row blocks this launch writes per channel)");
     if (p.alpha == 0.f) p.alpha = 1.f;
     p.splitk = 1;
     return lb_conv3x3_halo_eligible(p) == 32 ? launch_halo<128, 32>(p, stream) : launch_halo<128, 16>(p, stream);

@@ -521,6 +521,19 @@ extern "C" int lb_gemm_plan(const LbGemmParams* pp, int* tile, int* splitk, long
     return 0;
 }
 
+// Rows per sample of the LB_GEMM_CH_STATS buffer for the launch lb_gemm_f16 would make (same routing as below); 0 = no statistics.
+long lb_conv_halo_stat_rows_total(const LbGemmParams& p);
+extern "C" int lb_gemm_ch_stat_rows(const LbGemmParams* pp) {
+    if (pp == nullptr || !pp->conv || pp->M <= 0 || pp->Hout <= 0 || pp->Wout <= 0) return 0;
+    const LbGemmParams& p = *pp;
+    bool halo;
+    if (p.scatter == 2) halo = lb_upconv_halo_eligible(p) != 0;
+    else halo = !(g_halo != 0 && !g_force_tile && lb_conv3x3_narrow_eligible(p)) && use_halo(p);
+    if (!halo) return 0;
+    const long samples = (long)p.M / ((long)p.Hout * p.Wout);
+    return samples > 0 ? (int)(lb_conv_halo_stat_rows_total(p) / samples) : 0;
+}
+
 extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     LbGemmParams p = *pp;
     const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0;

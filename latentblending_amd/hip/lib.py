@@ -32,7 +32,7 @@ class LbGemmParams(C.Structure):
         ("stride", C.c_int), ("pad", C.c_int), ("ups", C.c_int), ("ldx", C.c_int),
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
         ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
-        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int), ("ch_stats", C.c_void_p),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int), ("ch_stats", C.c_void_p), ("ch_stats_rows", C.c_int),
     ]
 
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "lb_conv3x3_narrow_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_upconv2x_halo_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_conv_halo_set_persistent": (None, [_i]),
+    "lb_gemm_ch_stat_rows": (_i, [C.POINTER(LbGemmParams)]),
     "lb_conv_halo_plan": (None, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "lb_gemm_plan": (_i, [C.POINTER(LbGemmParams), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long)]),
     "lb_groupnorm_workspace_bytes": (_l, [_i, _i]),
@@ -124,7 +125,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

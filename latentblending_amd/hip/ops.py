@@ -206,7 +206,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
         p.ln_colsum, p.ln_eps = ln[0].data_ptr(), float(ln[1])
     if ch_stats is not None:                          # halo-tile convs only: GroupNorm statistics of the stored output
         p.flags |= lib.GEMM_CH_STATS
-        p.ch_stats = ch_stats.data_ptr()
+        p.ch_stats, p.ch_stats_rows = ch_stats.data_ptr(), ch_stats.shape[1]      # [N][B * rows][2] fp32
     ws = None
     if splitk_ws and not (flags & lib.GEMM_GEGLU) and ln is None:
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)
@@ -250,6 +250,18 @@ def conv_halo_plan(B: int, H: int, W: int, cin: int, cout: int, ks: int = 3):
     kind, tw, items, grid = C.c_int(), C.c_int(), C.c_long(), C.c_long()
     api.lb_conv_halo_plan(C.byref(p), C.byref(kind), C.byref(tw), C.byref(items), C.byref(grid))
     return kind.value, tw.value, items.value, grid.value
+
+
+def conv_ch_stat_rows(B: int, H: int, W: int, cin: int, cout: int, ks: int = 3) -> int:
+    """Row blocks per sample of the LB_GEMM_CH_STATS buffer a 3x3 conv (ks = 3) / one-launch sub-pixel upsampler conv (ks = 2) of
+    this geometry writes when ``gemm`` launches it (lb_gemm_ch_stat_rows: the library's own routing and tile constants); 0 = it
+    does not run on a halo-tile kernel."""
+    p = LbGemmParams()
+    p.conv, p.M, p.N, p.K = 1, B * H * W, cout, ks * ks * cin
+    p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.KH, p.KW, p.stride, p.ldx = H, W, H, W, cin, ks, ks, 1, cin
+    p.pad, p.scatter = (1, 0) if ks == 3 else (0, 2)
+    p.zero_page = 64
+    return int(api.lb_gemm_ch_stat_rows(C.byref(p)))
 
 
 def groupnorm_from_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,

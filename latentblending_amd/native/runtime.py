@@ -201,7 +201,7 @@ class Emitter:
         if ch_stats is not None:       # halo-tile convs only (see halo_stat_rows): GroupNorm statistics of the stored output
             assert conv is not None and ch_stats.dtype == F32
             p.flags |= lib.GEMM_CH_STATS
-            p.ch_stats = ch_stats.data_ptr()
+            p.ch_stats, p.ch_stats_rows = ch_stats.data_ptr(), ch_stats.shape[1]    # [N][B * rows][2]: checked by the launcher
         if splitk and not (flags & lib.GEMM_GEGLU) and ln is None:
             p.partial = _p(self._gemm_ws(M, N))
         api.lb_gemm_f16(C.byref(p), _stream())
@@ -230,19 +230,9 @@ class Emitter:
         p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.KH, p.KW, p.stride, p.ldx = H, W, H, W, cin, ks, ks, 1, cin
         p.pad, p.scatter = (1, 0) if ks == 3 else (0, 2)
         p.zero_page = self.zero_page.data_ptr()
-        if ks == 3:
-            t, sk, nb = C.c_int(), C.c_int(), C.c_long()
-            api.lb_gemm_plan(C.byref(p), C.byref(t), C.byref(sk), C.byref(nb))
-            if t.value != 6:
-                return 0
-        elif not self.upconv_one_launch(B, H, W, cin, cout):
+        if ks == 2 and not self.upconv_one_launch(B, H, W, cin, cout):
             return 0
-        kind, tw, items, grid = C.c_int(), C.c_int(), C.c_long(), C.c_long()
-        api.lb_conv_halo_plan(C.byref(p), C.byref(kind), C.byref(tw), C.byref(items), C.byref(grid))
-        if kind.value != ks:
-            return 0
-        n_blocks = (cout + 127) // 128
-        return int(items.value // n_blocks // B * 4)
+        return int(api.lb_gemm_ch_stat_rows(C.byref(p)))      # the library's own routing + tile constants (0: not a halo launch)
 
     @staticmethod
     def upconv_one_launch(B: int, H: int, W: int, cin: int, cout: int) -> bool:

@@ -782,6 +782,19 @@ def test_halo_conv_persistent_work_split(B, H, W, Cin, N, ks):
         if keys:
             assert keys == {(bid % n_blocks, (bid // n_blocks) & 3 if ks == 2 else 0)}
     assert len(seen) == items.value
+    # LB_GEMM_CH_STATS: the statistics rows per sample come from the library (its routing + its tile constants), never from a
+    # host-side restatement: (items / channel blocks) * 4 wave rows over the samples when lb_gemm_f16 would route the conv to
+    # the halo kernel (3x3: only chip-filling grids under the default lb_gemm_set_halo(1)), else 0
+    rows = lib.api.lb_gemm_ch_stat_rows(ctypes.byref(p))
+    tile = ctypes.c_int()
+    lib.api.lb_gemm_plan(ctypes.byref(p), ctypes.byref(tile), None, None)
+    if ks == 2 or tile.value == 6:
+        assert rows == items.value // n_blocks * 4 // B > 0
+    else:
+        assert rows == 0
+    p.KH = p.KW = 1                                      # not a halo conv at all
+    p.K, p.pad, p.scatter = Cin, 0, 0
+    assert lib.api.lb_gemm_ch_stat_rows(ctypes.byref(p)) == 0
 
 
 def test_negative_prompt_semantics_follow_diffusers(cpu_backend):

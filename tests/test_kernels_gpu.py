@@ -760,11 +760,14 @@ def test_conv_channel_stats_and_groupnorm_from_them(case, results_log):
     wp = o.pack_conv_weight(w, Cin).to(DEV)
     kind, tw, items, grid = o.conv_halo_plan(B, H, H, Cin, Cout)
     assert kind == 3
-    rows = items // ((Cout + 127) // 128) // B * 4
-    st = torch.full((Cout, B * rows, 2), float("nan"), dtype=torch.float32, device=DEV)          # channel-major
     flags = l.GEMM_OUT_F32 if f32 else 0
     l.api.lb_gemm_set_halo(2)
     try:
+        rows = o.conv_ch_stat_rows(B, H, H, Cin, Cout)
+        assert rows == items // ((Cout + 127) // 128) // B * 4 > 0
+        st = torch.full((Cout, B * rows, 2), float("nan"), dtype=torch.float32, device=DEV)          # channel-major
+        with pytest.raises(RuntimeError):                       # a buffer of any other size is refused before anything is launched
+            o.gemm(xn, wp, bias=b.to(DEV), flags=flags, conv=dict(KH=3, KW=3, stride=1, pad=1), ch_stats=st[:, :-1])
         y = o.gemm(xn, wp, bias=b.to(DEV), residual=None if res is None else res.to(DEV), flags=flags, alpha=0.5,
                    conv=dict(KH=3, KW=3, stride=1, pad=1), ch_stats=st)
         y_plain = o.gemm(xn, wp, bias=b.to(DEV), residual=None if res is None else res.to(DEV), flags=flags, alpha=0.5,
