@@ -56,16 +56,25 @@ __device__ __forceinline__ void slerp_weights(double dot, double n0sq, double n1
     w1 = sin(tt) / st;
 }
 
-// The weights are a few hundred dependent float64 instructions (sqrt, acos, three sin, divisions): ONE thread
-// evaluates them and publishes them through LDS while the other waves of the block sleep at the barrier, so the
-// CU's VALU stays free for the other resident blocks (every thread used to evaluate them redundantly).
+// The weights are a few hundred dependent float64 instructions (sqrt, acos, three sin, divisions).  Wave 0 evaluates them and
+// publishes them through LDS while the other waves of the block sleep at the barrier (the CU's VALU stays free for the other
+// resident blocks); its lanes 0, 1, 2 take ONE of the three sines each - same functions on the same arguments as the
+// sequential chain (slerp_weights), so the weights are the same bits, two sine latencies sooner.
 __device__ __forceinline__ void slerp_weights_block(double dot, double n0sq, double n1sq, double fract,
                                                     double& w0, double& w1, double* red) {
-    if (threadIdx.x == 0) {
-        double a, b;
-        slerp_weights(dot, n0sq, n1sq, fract, a, b);
-        red[52] = a;
-        red[53] = b;
+    if (threadIdx.x < LB_WAVE) {
+        double c = dot / (sqrt(n0sq) * sqrt(n1sq));
+        const double lim = 1.0 - 1e-7;
+        c = c > lim ? lim : (c < -lim ? -lim : c);   // NaN passes through, as torch.clamp does
+        const double theta = acos(c);
+        const double tt = theta * fract;
+        const int l = threadIdx.x;
+        const double s = sin(l == 0 ? theta : (l == 1 ? theta - tt : tt));
+        const double st = __shfl(s, 0, LB_WAVE), sa = __shfl(s, 1, LB_WAVE), sb = __shfl(s, 2, LB_WAVE);
+        if (l == 0) {
+            red[52] = sa / st;
+            red[53] = sb / st;
+        }
     }
     __syncthreads();
     w0 = red[52];
@@ -155,8 +164,13 @@ __global__ void __launch_bounds__(512) slerp_batched_kernel(const T* __restrict_
 // (profiles/r02_slerp_study.txt): ~0.2 % of the elements need the chain, i.e. one wave-iteration in eight, and the
 // compiler keeps both paths' operands live.  Not kept; the float64 chain below is the product path.)
 // VPT 16-byte vectors of both inputs in REGISTERS between the reduction and the weighted sum: HBM is read exactly
-// once (6 B / element) without an LDS round trip, the block needs 0.5 KiB of LDS, so four 512-thread blocks share a
-// CU and one block's loads overlap another's float64 arithmetic.
+// once (6 B / element) without an LDS round trip and the block needs 0.5 KiB of LDS.  Only the RAW halves stay live across the
+// reduction: the weighted sum converts them to float64 again (an opaque asm between the two phases stops the compiler from keeping
+// the 64 converted doubles = 128 VGPRs of the first phase; rounds 1-3 shipped that form: 172 VGPRs at VPT = 4, ONE block per
+// CU, its load / reduce / weights / sum / store phases strictly one after the other - 3.06 TB/s by rocprofv3).  Now <= 80
+// VGPRs: three 512-thread blocks share a CU and one block's loads and stores overlap another's float64 arithmetic -
+// 4.34 TB/s (profiles/r04_mixing_rocprof.json).  Forcing 64 VGPRs (four blocks per CU, one spilled register) measured
+// no better (4.1-4.3 TB/s): what is left is the ~28 VALU instructions per element of the float64 chain.
 // STUDY (only instantiated with -DLB_STUDY_BUILD, tools/slerp_study.py): 0 = product; 1 = lerp weights instead of the
 // acos / sin chain; 2 = fp32 weighted sum (NOT exact)
 template <int VPT, int STUDY = 0>
@@ -190,6 +204,8 @@ __global__ void __launch_bounds__(512) slerp_strided_kernel(const f16* __restric
     double w0, w1;
     if (STUDY == 1) { w1 = fracts[b] + 1e-30 * dot; w0 = 1.0 - w1; }
     else slerp_weights_block(dot, s0, s1, fracts[b], w0, w1, red);
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) asm volatile("" : "+v"(va[j]), "+v"(vb[j]));       // (see above: re-convert, do not keep)
 #pragma unroll
     for (int j = 0; j < VPT; ++j) {
         const long i = threadIdx.x + (long)j * 512;
