@@ -189,6 +189,7 @@ typedef struct LbAttnParams {
     float scale;         /* 1/sqrt(D) */
     int causal;          /* 1: key k is visible to query q only when k <= q (CLIP text towers); needs Sq == Skv */
     const void* zero_page;          /* >= 16 zero bytes, 16-B aligned: source of the direct-to-LDS loads of rows >= Skv */
+    int reserved_;                  /* set by the launcher */
 } LbAttnParams;
 int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
 /* head dim 512, no causal form: the VAE decoder's mid-block attention (AutoencoderKL.decode, diffusers_holder.py:135) as ONE launch -
@@ -196,7 +197,8 @@ int lb_attn_fwd_d64(const LbAttnParams* params, void* stream);
  * 512 MB at 1024^2) */
 int lb_attn_fwd_d512(const LbAttnParams* params, void* stream);
 void lb_attn_set_tuning(int force);   /* testing: 0 = by shape; bits 0-1 = query groups per wave (1 / 2), bit 4 = always stream 64-key tiles,
-                                       * bit 5 = 5-stage ring for the streaming form (A/B knob) */
+                                       * bit 5 = 5-stage ring for the streaming form (A/B knob),
+                                       * bit 6 = the former two-stage form of the one-tile kernel, bit 7 = 8-byte output stores */
 int lb_softmax_rows_f16(void* x, int M, int N, int ld, float scale, void* stream);
 
 /* ---- small kernels ----------------------------------------------------------------- */

@@ -63,6 +63,8 @@ template <int N> __device__ __forceinline__ void att_tr_wait() {
 }
 __device__ __forceinline__ unsigned att_lds_addr(const void* p) { return (unsigned)(unsigned long)(att_lptr_t)p; }
 
+typedef _Float16 att_h2 __attribute__((ext_vector_type(2)));
+
 template <int KT, int QG, int NS>
 __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p) {
     constexpr int NKB = KT / 16;            // 16-key blocks of S^T per tile
@@ -122,7 +124,7 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_tile(s, s);
+    for (int s = 0; s < (NS > 1 ? NS - 1 : 1); ++s) issue_tile(s, s);       // (NS == 1: the single-tile form, its one tile)
 
     // ---- loop-invariant LDS offsets (halves, relative to the stage base) ----
     // K fragment (a operand): row kb*16 + l16, logical chunk s*4 + g
@@ -155,8 +157,8 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
 
     int st = 0;
     for (int t = 0; t < nt; ++t) {
-        att_wait_vm_barrier<(NS - 2) * NL>();     // tile t landed everywhere; stage (t-1) % NS is free everywhere
-        {
+        att_wait_vm_barrier<(NS > 1 ? NS - 2 : 0) * NL>();     // tile t landed everywhere; stage (t-1) % NS is free everywhere
+        if constexpr (NS > 1) {
             int refill = st - 1;
             if (refill < 0) refill += NS;
             issue_tile(t + NS - 1, refill);       // (masked to the zero page past the end: the counts stay constant)
@@ -270,17 +272,41 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before the block may exit
 
+    // Output: lane (g, l16) holds O[q = l16][d = 16 dt + 4 g + r].  WIDE form (p.reserved_ & 1: ldo % 8 == 0, O 16-byte aligned): the
+    // quads of dt and dt + 1 are paired with the neighbouring 16-lane row through v_permlane16_swap (the exchange of the GEMM
+    // epilogue, lb_gemm.h), so that every lane owns 8 CONSECUTIVE halves: two 16-byte stores per query group instead of four 8-byte ones.
+    const bool wide = (p.reserved_ & 1) != 0;
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
         const float l = lt[qg][0];                                 // (every row of the ones-block holds the same sum)
         const float inv = l > 0.f ? 1.f / l : 0.f;
         const int q_row = q0 + qg * 16 + l16;
+        f16* orow = O + ((long)b * p.Sq + (q_row < p.Sq ? q_row : p.Sq - 1)) * p.ldo + h * ATT_D;
+        if (wide) {                                                // (wave-uniform; every lane takes part in the exchange)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                unsigned u[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f32x4 a = ot[qg][2 * pr + k];
+                    u[k][0] = __builtin_bit_cast(unsigned, (att_h2){(f16)(a[0] * inv), (f16)(a[1] * inv)});
+                    u[k][1] = __builtin_bit_cast(unsigned, (att_h2){(f16)(a[2] * inv), (f16)(a[3] * inv)});
+                }
+                const auto r0 = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
+                const int n = (2 * pr + 1) * 16 + 4 * g;
+                const int nst = (g & 1) ? n - 4 : n - 16;
+                typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+                if (q_row < p.Sq) *reinterpret_cast<att_u4*>(orow + nst) = (att_u4){r0[0], r1[0], r0[1], r1[1]};
+            }
+            continue;
+        }
         if (q_row < p.Sq) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const f16x4 o = {(f16)(ot[qg][dt][0] * inv), (f16)(ot[qg][dt][1] * inv), (f16)(ot[qg][dt][2] * inv),
                                  (f16)(ot[qg][dt][3] * inv)};
-                *reinterpret_cast<f16x4*>(O + ((long)b * p.Sq + q_row) * p.ldo + h * ATT_D + dt * 16 + 4 * g) = o;
+                *reinterpret_cast<f16x4*>(orow + dt * 16 + 4 * g) = o;
             }
         }
     }
@@ -303,12 +329,21 @@ static void attn_launch(const LbAttnParams& p, hipStream_t s) {
 static int g_attn_force = 0;
 extern "C" void lb_attn_set_tuning(int force) { g_attn_force = force; }
 
-static int attn_dispatch(const LbAttnParams& p, int force, hipStream_t s) {
+static int attn_dispatch(const LbAttnParams& pin, int force, hipStream_t s) {
+    LbAttnParams p = pin;
+    p.reserved_ = (!(force & 128) && p.ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(p.O) & 15) == 0) ? 1 : 0;    // 16-byte output stores
     // short sequences (cross-attention: 80 context rows) sit in ONE 96-key tile; long ones stream 64-key tiles
     const bool single = p.Skv <= 96 && !(force & 16);
+    const long blocks128 = (long)((p.Sq + 127) / 128) * p.H * p.B;
     int qg = force & 3;
-    if (qg == 0) qg = (long)((p.Sq + 127) / 128) * p.H * p.B >= 384 ? 2 : 1;   // 128-row blocks once they fill the chip
-    if (single) { if (qg == 2) attn_launch<96, 2, 2>(p, s); else attn_launch<96, 1, 2>(p, s); }
+    if (qg == 0) qg = blocks128 >= 384 ? 2 : 1;   // 128-row blocks once they fill the chip
+    // The one-tile form needs no ring: ONE stage (24 KiB of LDS, nothing but the tile itself requested - the two-stage form
+    // spent a tile's worth of zero-page requests and LDS on a refill that never comes).  Beyond ~4 rounds of 128-row blocks the
+    // 64-row blocks (81 VGPRs: five blocks per CU instead of three) quantise better.  MI355X, B = 17 (profiles/r04_attn_ab.txt):
+    // cross S = 1024: 18.1 -> 15.2 us, cross S = 256: 11.0 -> 10.2 us.  Bit 6 of `force` = the former two-stage form (A/B).
+    if (single && !(force & 3) && blocks128 >= 1024) qg = 1;
+    if (single && !(force & 64)) { if (qg == 2) attn_launch<96, 2, 1>(p, s); else attn_launch<96, 1, 1>(p, s); }
+    else if (single) { if (qg == 2) attn_launch<96, 2, 2>(p, s); else attn_launch<96, 1, 2>(p, s); }
     else if (force & 32) { if (qg == 2) attn_launch<64, 2, 5>(p, s); else attn_launch<64, 1, 5>(p, s); }
     else        { if (qg == 2) attn_launch<64, 2, 3>(p, s); else attn_launch<64, 1, 3>(p, s); }
     return lb_check_launch("lb_attn_fwd_d64");

@@ -41,7 +41,7 @@ class LbAttnParams(C.Structure):
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("Sq", C.c_int), ("Skv", C.c_int), ("Skv_valid", C.c_int),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int),
-        ("scale", C.c_float), ("causal", C.c_int), ("zero_page", C.c_void_p),
+        ("scale", C.c_float), ("causal", C.c_int), ("zero_page", C.c_void_p), ("reserved_", C.c_int),
     ]
 
 

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import io
 import struct
+import warnings
 from typing import List
 
 import numpy as np
@@ -37,6 +38,11 @@ except Exception:
 
         def __init__(self, fp_out: str, fps: int = 30, shape_hw=None, quality: int = 92, **_):
             self.fp_out = fp_out
+            self.container = "avi-mjpeg"          # whatever the extension of fp_out says (the caller's path is kept: drop-in)
+            if not str(fp_out).lower().endswith(".avi"):
+                warnings.warn(f"lunar_tools / ffmpeg are not installed: '{fp_out}' will hold a Motion-JPEG AVI stream (RIFF 'AVI ' "
+                              "header), not the container its extension names; ffmpeg / VLC / mpv detect it by content, "
+                              "latentblending_amd.movie.read_movie_header / read_movie_jpegs read it back", UserWarning, stacklevel=2)
             self.fps = int(fps)
             self.shape_hw = list(shape_hw) if shape_hw is not None else None
             self.quality = quality

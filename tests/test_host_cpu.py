@@ -449,7 +449,10 @@ def test_movie_concatenation_and_lunar_tools_facade(tmp_path):
     means = [float(np.asarray(Image.open(io.BytesIO(j))).mean()) for j in jp]
     assert np.allclose(means, [0, 10, 20, 40, 50, 60, 70, 80], atol=1.5)
     bad = str(tmp_path / "other.mp4")
-    s = movie.MovieSaver(bad, fps=9, shape_hw=[16, 24]); s.write_frame(np.zeros((16, 24, 3), np.uint8)); s.finalize()
+    with pytest.warns(UserWarning, match="Motion-JPEG AVI"):          # the fallback writer says what the file really holds
+        s = movie.MovieSaver(bad, fps=9, shape_hw=[16, 24])
+    assert s.container == "avi-mjpeg"
+    s.write_frame(np.zeros((16, 24, 3), np.uint8)); s.finalize()
     with pytest.raises(AssertionError):
         movie.concatenate_movies(fp_all, [parts[0], bad])
 

@@ -449,7 +449,8 @@ def test_attention_d64(case, results_log):
 
 
 # (49 / 50 = bit 5: the 5-stage-ring A/B form added at the end of round 3 without a GPU run: opt in with LB_TEST_EXPERIMENTAL=1)
-@pytest.mark.parametrize("force", [1, 2, 17, 18] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
+# (bit 6 = the former two-stage form of the one-tile kernel, bit 7 = 8-byte output stores instead of the paired 16-byte ones)
+@pytest.mark.parametrize("force", [1, 2, 17, 18, 65, 66, 129, 130] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
 @pytest.mark.parametrize("case", [(2, 3, 300, 300, 300), (2, 2, 130, 80, 77), (1, 2, 70, 96, 90), (1, 1, 16, 8, 5)])
 def test_attention_d64_variants(case, force, results_log):
     """Every kernel variant (1 / 2 query groups per wave, single 96-key tile / streamed 64-key tiles) on ragged shapes,
@@ -471,6 +472,13 @@ def test_attention_d64_variants(case, force, results_log):
     finally:
         l.api.lb_attn_set_tuning(0)
     check_close(results_log, f"attn_f{force}_{'_'.join(map(str, case))}", got.reshape(B, Sq, C), ref, floor=2e-3)
+    if force & 128:                 # the paired 16-byte stores (default) hold the same values (the 8-byte form rounds two of four
+        l.api.lb_attn_set_tuning(force & ~128)     # halves through v_fma_mixlo_f16, i.e. once instead of twice: <= 1 fp16 ulp apart)
+        try:
+            wide = o.attention_d64(qd, kd, vd, B, H, Sq, Skv, valid)
+        finally:
+            l.api.lb_attn_set_tuning(0)
+        assert float((wide.float() - got.float()).abs().max()) <= 2.0 ** -10 * max(1.0, float(got.float().abs().max()))
 
 
 @pytest.mark.parametrize("force", [0, 1, 2, 17])

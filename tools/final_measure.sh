@@ -26,7 +26,7 @@ cp profiles/${TAG}_rocprof_summary.json $OUT/ 2>/dev/null
 # keep the per-kernel summaries, drop the raw traces
 for f in $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" -o -name "*domain_stats.csv"); do cp $f $OUT/${TAG}_bench_$(basename $f | sed 's/^[0-9]*_//'); done
 find $OUT/${TAG}_stats $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -type f -size +2M -delete 2>/dev/null
-timeout 400 python bench.py $ARGS > $OUT/${TAG}_bench_1gpu.json 2> $OUT/${TAG}_bench_1gpu.err
+timeout 1200 python bench.py $ARGS > $OUT/${TAG}_bench_1gpu.json 2> $OUT/${TAG}_bench_1gpu.err
 echo "bench rc=$?"; tail -c 600 $OUT/${TAG}_bench_1gpu.json | head -c 600; echo
 # (the skewed-metric and cfg-3 lines are part of the bench line itself since round 3: "secondary")
 # rocprof-reported GB/s of the mixing / scheduler kernels on >= 1 GiB batches
