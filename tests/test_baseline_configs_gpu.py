@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from oracle import pipe as OP  # noqa: E402  (checker only: the noise tape and the tiny configs)
 from oracle import sdxl_ref as R  # noqa: E402
 
-from _baseline_cfgs import (check_structure, check_structure_cfg4_batched, check_values, gold_configs, setup_cfg3,  # noqa: E402
+from _baseline_cfgs import (check_cfg4_sequential, check_structure, check_structure_cfg4_batched, check_values, gold_configs, setup_cfg3,  # noqa: E402
                             setup_cfg4, setup_cfg5)
 
 GPU_TOL = dict(sim_rtol=5e-2, norm_rtol=3e-2, mean_tol=1.0, head_tol=4)
@@ -61,12 +61,12 @@ def test_cfg4_stated_tree_native(frontier, results_log):
     tape.reset()
     imgs = be.run_transition(fixed_seeds=[420, 421])
     assert len(imgs) == 66
-    if frontier == 1:
-        check_structure(be, imgs, c)
-        check_values(be, imgs, c, **GPU_TOL)
+    same = True
+    if frontier == 1:       # (identical tree, or the 64th split on a near tie of the reference's choice: see check_cfg4_sequential)
+        same = check_cfg4_sequential(be, imgs, c, GPU_TOL)
     else:                   # (a batched frontier consumes the ancestral noise tape in evaluation order, not in commit order)
         check_structure_cfg4_batched(be, imgs, c)
-    results_log[f"cfg4_stated_tree_frontier{frontier}"] = {"frames": len(imgs), "same_tree": True,
+    results_log[f"cfg4_stated_tree_frontier{frontier}"] = {"frames": len(imgs), "same_tree": same,
                                                            "rounds": be.stats.get("frontier_rounds", 0)}
 
 

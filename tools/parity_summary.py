@@ -32,6 +32,15 @@ rows = [
     ("branch farm: two native ranks on one GPU (frontier 8)", "farm_native_2ranks"),
     ("... frontier 1 (rank 1 owns no mid branch)", "farm_native_2ranks_frontier1"), ("... frontier 3 (2 / 1 split)", "farm_native_2ranks_frontier3"),
     ("branch farm on RCCL, world 1", "farm_rccl_world1"),
+    ("cfg 3 stated tree (30 steps, depth 0.5, 15 branches, guidance 4.0) at tiny width, frontier 1, vs tests/golden/configs.json", "cfg3_stated_tree_frontier1"),
+    ("... frontier 16", "cfg3_stated_tree_frontier16"),
+    ("cfg 4 stated tree (Turbo, 64 branches), sequential engine", "cfg4_stated_tree_frontier1"),
+    ("... frontier 64 (fused wavefront + virtual gaps)", "cfg4_stated_tree_frontier64"),
+    ("cfg 5: 6-prompt chain (swap_forward + recycle_img1) through replay.run_multi_transition, frontier 1", "cfg5_chain_frontier1"),
+    ("... frontier 16", "cfg5_chain_frontier16"),
+    ("get_state_dict -> yml_save -> load_state_dict -> run_transition on the native pipe", "state_round_trip_native"),
+    ("two-stage speculation vs all-at-once, the benchmark's metric", "two_stage_speculation_skew0.0"),
+    ("... skewed metric exp(3 x position)", "two_stage_speculation_skew3.0"),
 ]
 out = [header] if header else []
 out.append(f"# Source: {src} written by tests/conftest.py::results_log ({len(d)} entries); selection below.\n")
