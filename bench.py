@@ -747,7 +747,10 @@ def _run():
                    "farm": None if farm is None else {
                        "collectives_per_transition": farm.collectives / max(args.steps + args.warmup, 1),
                        "bytes_moved_per_transition": farm.bytes_moved / max(args.steps + args.warmup, 1),
-                       "ms_per_transition_by_rank": per_rank_ms},
+                       "ms_per_transition_by_rank": per_rank_ms,
+                       "expected_strong_scaling": "Amdahl-limited by design: the two B=2 anchor steps (2 x 11.7 ms of a 151 ms transition on one GPU) "
+                                                  "and the anchors' share of the B = 2 + G/N batches do not shard - about 2.3-2.5x at 8 GPUs for cfg 2 "
+                                                  "(DESIGN.md section 5); --scaling weak (15 N branches) is the sharded regime"},
                    "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1),
                    "cold_start_s": None if cold_start_s is None else round(cold_start_s, 2)},
     }
