@@ -76,6 +76,8 @@ class BlendingEngine:
         self.pair_metric = None             # optional callable(frame_a, frame_b, fract_a, fract_b) -> distance replacing the
         #                                     LPIPS metric on every path (policy stress tests: bench.py --metric-skew, tests)
         self.speculate_virtual = True       # frontier mode: also evaluate children of not-yet-existing gaps
+        self.speculation_oversubscribe = 1.0   # frontier rounds after the first: evaluate this many candidates per branch still missing
+        self.learn_child_ratio = True          # frontier: predict a virtual gap's distances from the ratios child / parent measured so far
         self.two_stage_speculation = False  # fused first round (single-level trees): False = ALL stems at once in level order - one
         #                                     round when the metric is balanced, several small latency-bound rounds and dropped
         #                                     branches when it is not; True = only the complete top levels of the binary splitting
@@ -649,9 +651,24 @@ class BlendingEngine:
         in ``ready`` until the reference's greedy order asks for their gap; whatever is never asked
         for is dropped at the end of the level."""
         import heapq
+        import math
         tree = self._tree
         ready = dict(ready) if ready else {}     # (f_left, f_right) -> dict(fract, traj, frame, sl, sr)
         remaining = stems
+        ratio_l, ratio_r = [], []                # measured (child-to-left-end, child-to-right-end) distance / parent gap distance
+
+        def learn(key, r, parent):               # one sample per evaluated child whose parent gap distance is known
+            if parent is not None and parent is not UNSCORED and float(parent) > 0 and math.isfinite(float(parent)):
+                ratio_l.append(float(r["sl"]) / float(parent))
+                ratio_r.append(float(r["sr"]) / float(parent))
+
+        def virtual_parent(fl, fr):              # distance of the not-yet-real gap (fl, fr): a half of an evaluated child's gap
+            width = fr - fl
+            for key in ((fl, fr + width), (fl - width, fr)):
+                r = ready.get(key)
+                if r is not None and r["fract"] in (fl, fr):
+                    return r["sl"] if r["fract"] == fr else r["sr"]
+            return None
         while remaining > 0:
             # 1) commit everything the greedy order can already consume
             progressed = True
@@ -661,12 +678,26 @@ class BlendingEngine:
                 key = (tree.fracts[gap], tree.fracts[gap + 1])
                 if key in ready:
                     r = ready.pop(key)
+                    learn(key, r, tree.similarities[gap])
                     tree.commit(r["fract"], idx_injection, r["traj"], r["frame"], r["sl"], r["sr"])
                     remaining -= 1
                     progressed = True
             if remaining == 0:
                 break
-            # 2) pick what to evaluate next: best-first over real + virtual gaps
+            # 2) pick what to evaluate next: best-first over real + virtual gaps.  A virtual gap's distance is PREDICTED from its
+            #    parent's: parent x the median ratio measured on this level so far (left and right halves separately: a metric
+            #    that grows along the transition bends the tree, and the halves of a gap are not equally wide in its eyes);
+            #    parent / 2 until something was measured.
+            r_l = r_r = 0.5
+            if self.learn_child_ratio:
+                samples_l, samples_r = list(ratio_l), list(ratio_r)
+                for (fl, fr), r in ready.items():          # evaluated, not yet committed: their parents may be virtual themselves
+                    par = virtual_parent(fl, fr)
+                    if par is not None and float(par) > 0:
+                        samples_l.append(float(r["sl"]) / float(par))
+                        samples_r.append(float(r["sr"]) / float(par))
+                if samples_l:
+                    r_l, r_r = sorted(samples_l)[len(samples_l) // 2], sorted(samples_r)[len(samples_r) // 2]
             heap, tick = [], 0
             unscored = any(s is UNSCORED for s in tree.similarities)
             for g in range(len(tree.fracts) - 1):
@@ -674,9 +705,17 @@ class BlendingEngine:
                 heap.append((-est, tick, tree.fracts[g], tree.fracts[g + 1], g))
                 tick += 1
             heapq.heapify(heap)
-            budget = min(self.frontier_width, max(1, remaining - len(ready)))
-            specs = []
-            while heap and len(specs) < budget:
+            # Walk the greedy order FORWARD on exact + predicted distances: every pop is one commit the reference's loop would make
+            # next - a child already evaluated (`ready`: consumed virtually, its halves carry exact distances) or a candidate to
+            # evaluate now.  `remaining` pops = exactly the candidates this level still needs if the predictions hold (evaluated
+            # children the greedy order never asks for do not count: round 3 charged them against the budget and crawled one
+            # candidate per round under a skewed metric); `speculation_oversubscribe` > 1 walks further, so that a near miss
+            # is already covered (small batches cost little more than one sample).
+            over = 1.0 if unscored else float(self.speculation_oversubscribe)      # (a blind first round gains nothing from guessing further)
+            target = max(remaining, int(math.ceil(remaining * over)))
+            specs, pops = [], 0
+            while heap and pops < target and len(specs) < self.frontier_width:
+                pops += 1
                 neg_est, _, fl, fr, g = heapq.heappop(heap)
                 mid = (fl + fr) / 2
                 if (fl, fr) in ready:                      # child known: its halves have exact distances
@@ -692,7 +731,7 @@ class BlendingEngine:
                         coeffs=planner.parental_crossfeed_coeffs(
                             self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
                             self.parental_crossfeed_range, self.parental_crossfeed_decay)))
-                    est_l = est_r = -neg_est / 2           # heuristic until the child exists
+                    est_l, est_r = -neg_est * r_l, -neg_est * r_r     # prediction until the child exists
                 if self.speculate_virtual:
                     for a, b, e in ((fl, mid, est_l), (mid, fr, est_r)):
                         heapq.heappush(heap, (-float(e), tick, a, b, g))

@@ -741,6 +741,46 @@ def test_speculative_frontier_equals_sequential_under_skewed_metric(skew, cpu_ba
     assert spec.stats["speculation_evaluated"] - spec.stats.get("speculation_dropped", 0) == 9
 
 
+@pytest.mark.parametrize("skew,power", [(3.0, 2.0), (-4.0, 2.0), (6.0, 1.0)])
+def test_frontier_second_round_walks_the_predicted_greedy_order(skew, power, cpu_backend):
+    """cfg-2-shaped tree (15 branches, frontier 16) under a metric that depends on the fractions only (|df|^power x exp(skew x
+    position): power 2 x skew 3 reproduces the rounds / evaluated counts the MI355X bench measured with the skewed LPIPS).
+    After the blind first round the engine walks the reference's greedy order forward on exact + predicted distances
+    (children already evaluated are consumed virtually; a virtual gap's halves are predicted from the child / parent ratios
+    measured so far): the level finishes in TWO rounds where the round-3 budget rule (branches missing minus evaluated
+    children, whether or not the greedy order would ever ask for them) crawled one candidate per round (4 - 9 rounds).
+    The tree is the sequential one under every setting of the two knobs."""
+    import math
+    from latentblending_amd import BlendingEngine
+
+    def run(width, **attrs):
+        p = tiny_pipe(turbo=True)
+        np.random.seed(0)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=width)
+        for k, v in attrs.items():
+            setattr(be, k, v)
+        be.pair_metric = lambda a, b, fa, fb: abs(fa - fb) ** power * math.exp(skew * 0.5 * (fa + fb))
+        be.set_dimensions((64, 64))
+        be.set_branching(nmb_max_branches=15)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        p.noise.reset()
+        be.run_transition(fixed_seeds=[420, 421])
+        return be
+    seq = run(1)
+    assert seq.tree_fracts != [i / 16 for i in range(17)]                  # the metric really bends the tree
+    spec = run(16)
+    assert spec.tree_fracts == seq.tree_fracts and spec.tree_idx_injection == seq.tree_idx_injection
+    assert spec.stats["frontier_rounds"] <= 3 and spec.stats["speculation_evaluated"] <= 24
+    if (skew, power) == (3.0, 2.0):
+        assert spec.stats["frontier_rounds"] == 2 and spec.stats["speculation_evaluated"] == 18
+    assert spec.stats["speculation_evaluated"] - spec.stats.get("speculation_dropped", 0) == 15
+    for attrs in (dict(learn_child_ratio=False), dict(speculation_oversubscribe=2.0), dict(speculate_virtual=False)):
+        other = run(16, **attrs)
+        assert other.tree_fracts == seq.tree_fracts, attrs
+        assert other.stats["speculation_evaluated"] - other.stats.get("speculation_dropped", 0) == 15
+
+
 @pytest.mark.parametrize("B,H,W,Cin,N,ks", [(17, 512, 512, 128, 128, 3), (17, 64, 64, 320, 320, 3), (17, 16, 16, 1280, 1280, 3),
                                             (2, 64, 64, 640, 320, 3), (17, 256, 256, 256, 256, 2), (3, 32, 32, 192, 640, 2),
                                             (1, 16, 16, 64, 64, 3)])
