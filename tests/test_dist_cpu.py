@@ -133,6 +133,56 @@ def test_branch_farm_cfg4_shape_at_world_8(tmp_path):
         assert r["sims"] == res[0]["sims"] and r["latent_sha"] == res[0]["latent_sha"] and r["frame_sha"] == res[0]["frame_sha"]
 
 
+def _skew_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import math
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    set_backend(R.TorchCpuBackend())
+
+    def run(width, farm):
+        p = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+        np.random.seed(0)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=width, farm=farm)
+        be.pair_metric = lambda a, b, fa, fb: abs(fa - fb) ** 2 * math.exp(3.0 * 0.5 * (fa + fb))
+        be.set_dimensions((64, 64))
+        be.set_branching(nmb_max_branches=15)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        p.noise.reset()
+        be.run_transition(fixed_seeds=[420, 421])
+        return be
+    farm = BranchFarm()
+    spec = run(16, farm)
+    seq = run(1, None)                       # (no collectives: every rank repeats the sequential engine for itself)
+    res = {"fracts": [float(f) for f in spec.tree_fracts], "seq_fracts": [float(f) for f in seq.tree_fracts],
+           "sims": [float(x) for x in spec.tree_similarities], "rounds": spec.stats.get("frontier_rounds", 0),
+           "evaluated": spec.stats.get("speculation_evaluated", 0), "collectives": farm.collectives}
+    json.dump(res, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_under_a_skewed_metric_walks_the_same_order_on_every_rank(tmp_path):
+    """The forward walk of the frontier (exact + predicted distances, ratios learned from exchanged scalars) is part of the
+    SPMD plan: under a metric that bends the tree both ranks must pick the same candidates in every round (else the packed
+    all-gathers would pair different branches), finish in two rounds and hold the sequential tree."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_skew_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r in res:
+        assert r["fracts"] == r["seq_fracts"] and r["fracts"] != [i / 16 for i in range(17)]
+        assert r["rounds"] == 2 and r["evaluated"] == 18 and r["collectives"] > 0
+    assert res[0]["sims"] == res[1]["sims"] and res[0]["fracts"] == res[1]["fracts"]
+
+
 def _chain_worker(rank, world, port, out_dir):
     """Two chained transitions (example_multi_trans.py:39-58: swap_forward + recycle_img1) with ancestral noise from a
     tape; world 1 = the farm-less engine in the same frontier mode."""
