@@ -2,7 +2,8 @@
 ring depth of the direct-to-LDS GEMMs (lb_gemm_set_variant(1, stages)) and the 5-stage attention ring (lb_attn_set_tuning(32)).
 The isolated sweeps (profiles/r03_small_m_sweep*.txt) ran with Infinity-Cache-warm weights; inside the program every GEMM
 streams its weights from HBM (5.1 GB per forward), so the latency picture differs - this tool measures it where it matters.
-Knobs are read when a program is RECORDED.  Prepared at the end of round 3 (no GPU minutes left): not yet run.
+Knobs are read when a program is RECORDED.  Prepared at the end of round 3, run at the end of round 4 with the ping-pong policy
+added as a knob (profiles/r04_unet_knob_ab.txt): one process, same weights, same box - the cleanest in-situ A/B there is.
 Usage: LB_SYNTH_CACHE=/tmp python tools/unet_knob_ab.py > gpurun_out/unet_knob_ab.txt"""
 import os
 import sys
@@ -17,12 +18,14 @@ KNOBS = [("default", lambda: None),
          ("gemm ring 2", lambda: lib.api.lb_gemm_set_variant(1, 2)),
          ("gemm ring 3", lambda: lib.api.lb_gemm_set_variant(1, 3)),
          ("gemm ring 4", lambda: lib.api.lb_gemm_set_variant(1, 4)),
-         ("attention 5-stage ring", lambda: lib.api.lb_attn_set_tuning(32))]
+         ("attention 5-stage ring", lambda: lib.api.lb_attn_set_tuning(32)),
+         ("ping-pong GEMM off", lambda: lib.api.lb_gemm_set_pp_auto(0))]
 
 
 def reset():
     lib.api.lb_gemm_set_variant(-1, 0)
     lib.api.lb_attn_set_tuning(0)
+    lib.api.lb_gemm_set_pp_auto(1)
 
 
 def timed(launch, iters):
