@@ -156,6 +156,7 @@ int lb_gemm_ch_stat_rows(const LbGemmParams* params);
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
 void lb_gemm_set_wide_store(int on);              /* tuning: 1 = 16-byte epilogue stores for fp16 row-major outputs (same results) */
+void lb_gemm_set_lean_epilogue(int on);           /* tuning: 1 (default) = one-round-trip tile epilogue where it applies, 0 = the per-row form everywhere (same results) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
 /* ---- normalisation (torch.nn.GroupNorm / LayerNorm inside the UNet / VAE modules reached

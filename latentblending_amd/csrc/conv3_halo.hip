@@ -306,13 +306,31 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         int col0 = n0 + wave_n * (BN / 2) + 4 * g;
         asm volatile("" : "+v"(col0));
         if (!(study & 1)) {
+            // geometry of the one-round-trip epilogue (lb_gemm.h): the tile's rows all exist and lie inside ONE image; output
+            // rows relative to the tile's first output pixel (for KS == 2 on the 2x grid, at this block's parity) are
+            // recomputed from the lane's local pixel index - compile-time shifts, nothing held across the MFMA loop
+            int tid_o = tid;                            // (opaque: nothing derived from it is hoisted out of the tile loop)
+            asm volatile("" : "+v"(tid_o));
+            auto out_rel = [&](int i) {
+                if constexpr (KS == 3) return mloc[i];
+                const int ml = (tid_o >> 7) * 64 + i * 16 + (tid_o & 15), ly = ml / TW, lx = ml - ly * TW;
+                return 4 * ly * p.Win + 2 * lx;
+            };
+            const long out_lo = KS == 3 ? (long)mbase
+                                        : ((long)(cur.b * 2 * p.Hin + 2 * cur.y0 + par_y)) * (2 * p.Win) + 2 * cur.x0 + par_x;
+            const int row_hi = mbase + (TH - 1) * p.Win + TW;
+            const int colw = col0 - 4 * ((tid_o & 63) >> 4);
             if (p.flags & LB_GEMM_CH_STATS) {   // (wave-uniform) GroupNorm statistics of the stored tile: row block (item / n_blocks) * 4 + wave_m
                 const long stat_rows = (long)(n_items / n_blocks) * 4;          // row blocks of the whole launch
                 float2* chst = reinterpret_cast<float2*>(p.ch_stats) + ((long)(item / n_blocks) * 4 + wave_m);
-                lb_gemm_tile_epilogue_rows_ln<TM, TN, false, false, true>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0,
-                                                                          (const LbLnRows<TM>*)nullptr, chst, stat_rows);
+                if (!lb_gemm_tile_epilogue_lean<TM, TN, true, true>(q, acc, [&](int i) { return mbase + mloc[i]; }, mbase, row_hi, out_rel,
+                                                                    out_lo, cur.b, colw, chst, stat_rows))
+                    lb_gemm_tile_epilogue_rows_ln<TM, TN, false, false, true>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0,
+                                                                              (const LbLnRows<TM>*)nullptr, chst, stat_rows);
             } else {
-                lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
+                if (!lb_gemm_tile_epilogue_lean<TM, TN, false, true>(q, acc, [&](int i) { return mbase + mloc[i]; }, mbase, row_hi, out_rel,
+                                                                     out_lo, cur.b, colw))
+                    lb_gemm_tile_epilogue_rows<TM, TN, false>(q, acc, [&](int i) { return mbase + mloc[i]; }, col0, 0);
             }
         }
         else if (acc[0][0][0] == 12345.678f) *(float*)p.C = acc[1][1][1] + acc[2][2][2] + acc[3][3][3];   // (keeps the MFMAs alive)
@@ -415,8 +433,10 @@ int lb_upconv_halo_launch(LbGemmParams p, hipStream_t stream) {
 }
 
 // nearest-2x upsample + 3x3 conv as ONE launch: W = [4][N][ldw] stacked sub-pixel kernels (parity py*2+px), C = [B][2H][2W][ldc]
+extern int g_lb_wide_store, g_lb_lean_epilogue;
 extern "C" int lb_upconv2x_halo_f16(const LbGemmParams* pp, void* stream) {
     LbGemmParams p = *pp;
+    p.reserved2_ = (g_lb_wide_store & 1) | (g_lb_lean_epilogue ? 2 : 0);
     LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_upconv2x_halo_f16: empty problem");
     LB_REQUIRE(lb_upconv_halo_eligible(p) != 0,
                "lb_upconv2x_halo_f16: needs scatter = 2, KH = KW = 2, stride 1, Cin % 64 == 0, W % 16 == 0, zero page, no residual");
@@ -450,10 +470,9 @@ int lb_conv3x3_halo_launch(LbGemmParams p, hipStream_t stream) {
     return lb_conv3x3_halo_eligible(p) == 32 ? launch_halo<128, 32>(p, stream) : launch_halo<128, 16>(p, stream);
 }
 
-extern int g_lb_wide_store;
 extern "C" int lb_conv3x3_halo_f16(const LbGemmParams* pp, void* stream) {
     LbGemmParams p = *pp;
-    p.reserved2_ = g_lb_wide_store & 1;
+    p.reserved2_ = (g_lb_wide_store & 1) | (g_lb_lean_epilogue ? 2 : 0);
     LB_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "lb_conv3x3_halo_f16: empty problem");
     LB_REQUIRE(lb_conv3x3_halo_eligible(p) != 0,
                "lb_conv3x3_halo_f16: needs a 3x3 / stride 1 / pad 1 conv, Cin % 64 == 0, W % 16 == 0, zero page");

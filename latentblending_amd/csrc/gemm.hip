@@ -361,6 +361,10 @@ extern "C" void lb_gemm_set_variant(int variant, int stages) {   // variant < 0:
 // 1 (default) = fp16 row-major epilogues store 16 B per lane (column-group pairs exchanged through v_permlane16_swap); 0 = 8-B stores
 int g_lb_wide_store = 1;     // measured: VAE decode B=17 45.9 -> 44.8 ms, UNet B=17 38.11 -> 37.69 ms, bit-identical (profiles/r03_wide_store_ab.txt)
 extern "C" void lb_gemm_set_wide_store(int on) { g_lb_wide_store = on; }
+// 1 (default) = tiles whose epilogue is "alpha, bias, row vector or fp16 residual, fp16 row-major out" take the one-round-trip form
+// (lb_gemm.h: lb_gemm_tile_epilogue_lean); 0 = the per-row form everywhere.  Bit-identical; read when a launch is issued / recorded.
+int g_lb_lean_epilogue = 1;
+extern "C" void lb_gemm_set_lean_epilogue(int on) { g_lb_lean_epilogue = on; }
 
 extern "C" long lb_gemm_workspace_bytes(int M, int N) {
     // enough for the largest split the heuristic can pick (<= 16 slabs)
@@ -558,7 +562,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
         LB_REQUIRE(p.lda >= p.K && !(p.flags & LB_GEMM_TRANS_OUT), "lb_gemm_f16: LB_GEMM_LN_A normalises whole rows of A");
     }
     if (p.alpha == 0.f) p.alpha = 1.f;
-    p.reserved2_ = g_lb_wide_store & 1;
+    p.reserved2_ = (g_lb_wide_store & 1) | (g_lb_lean_epilogue ? 2 : 0);
     if (p.scatter == 2) {       // all four sub-pixel parities in one launch: only the halo kernel implements it
         LB_REQUIRE(lb_upconv_halo_eligible(p) != 0, "lb_gemm_f16: scatter = 2 needs Cin % 64 == 0, W % 16 == 0, stacked [4][N][K] weights");
         LB_DISPATCH("lb_upconv2x_halo_f16", lb_upconv_halo_launch(p, s));

@@ -336,6 +336,20 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
                                                            n0 + wave_n * (BN / 64) * 16 + 4 * g, &ln);
         return;
     }
+    if constexpr (!GEGLU) {     // the one-round-trip form wherever it applies (lb_gemm.h); else the general epilogue below
+        const int row_lo = m0 + wave_m * WROWS, row_hi = row_lo + 16 * TM;
+        int batch = -1;
+        if (p.rowvec) {
+            const int last = (row_hi < p.M ? row_hi : p.M) - 1;
+            const int b0 = row_lo / p.rows_per_batch;
+            batch = (last >= row_lo && last / p.rows_per_batch == b0) ? b0 : -1;
+        }
+        const int r0 = row_lo + l16;
+        if (lb_gemm_tile_epilogue_lean<TM, TN, false, false>(p, acc, [r0](int i) { return r0 + i * 16; }, row_lo, row_hi,
+                                                             [l16](int i) { return l16 + i * 16; }, (long)row_lo, batch,
+                                                             n0 + wave_n * (BN / 2)))
+            return;
+    }
     lb_gemm_tile_epilogue<TM, TN, GEGLU>(p, acc, m0 + wave_m * WROWS + l16, n0 + wave_n * (BN / 2) + 4 * g,
                                          n0 + wave_n * (BN / 64) * 16 + 4 * g);
 }

@@ -304,6 +304,19 @@ __global__ void __launch_bounds__(512) gemm_f16_pp_kernel(const LbGemmParams p) 
         }
         return;
     }
+    if constexpr (!GEGLU) {     // the one-round-trip form wherever it applies (lb_gemm.h); else the general epilogue below
+        const int row_lo = m0 + wr * 128, row_hi = row_lo + 128;
+        int batch = -1;
+        if (p.rowvec) {
+            const int last = (row_hi < p.M ? row_hi : p.M) - 1;
+            const int b0 = row_lo / p.rows_per_batch;
+            batch = (last >= row_lo && last / p.rows_per_batch == b0) ? b0 : -1;
+        }
+        const int r0 = row_lo + l16;
+        if (lb_gemm_tile_epilogue_lean<8, 4, false, false>(p, acc, [r0](int i) { return r0 + i * 16; }, row_lo, row_hi,
+                                                           [l16](int i) { return l16 + i * 16; }, (long)row_lo, batch, n0 + wc * 64))
+            return;
+    }
     lb_gemm_tile_epilogue<8, 4, GEGLU>(p, acc, m0 + wr * 128 + l16, n0 + wc * 64 + 4 * g, n0 + wc * 32 + 4 * g);
 }
 

@@ -135,6 +135,16 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             bh[jp] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : zero4;
             bg[jp] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + half + nc) : zero4;
         }
+        f32x4 chs[LNA ? TP : 1], cgs[LNA ? TP : 1];      // LN_A column sums of the lane's column groups: loaded once per tile
+        if (LNA) {                                       // (round 5; inside the row loop every load also waited for the stores before it)
+#pragma unroll
+            for (int jp = 0; jp < TP; ++jp) {
+                const int n = gcol0 + jp * 16;
+                const int nc = n < half ? n : 0;
+                chs[jp] = *reinterpret_cast<const f32x4*>(p.ln_colsum + nc);
+                cgs[jp] = *reinterpret_cast<const f32x4*>(p.ln_colsum + half + nc);
+            }
+        }
         // WIDE stores (see below): output column groups jp and jp + 1 paired through v_permlane16_swap -> 16-byte stores
         const bool gwide = TP % 2 == 0 && (p.reserved2_ & 1) && (p.ldc & 7) == 0 &&
                            (gcol0 - 4 * ((threadIdx.x & 63) >> 4)) + 16 * TP <= half;
@@ -148,11 +158,7 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             for (int jp = 0; jp < TP; ++jp) {
                 const int n = gcol0 + jp * 16;
                 if (!gwide && n >= half) continue;
-                f32x4 ch = zero4, cg = zero4;       // (LN_A column sums: re-read per row, L1 hits, no registers held)
-                if (LNA) {
-                    ch = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
-                    cg = *reinterpret_cast<const f32x4*>(p.ln_colsum + half + n);
-                }
+                const f32x4 ch = LNA ? chs[LNA ? jp : 0] : zero4, cg = LNA ? cgs[LNA ? jp : 0] : zero4;
                 f16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -192,6 +198,15 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cs_s[j][r] = cs_q[j][r] = 0.f;
+    }
+    constexpr bool CS_HOIST = LNA && TN <= 4;   // (the 256-wide tiles have no 32 registers to spare: they keep the per-group loads)
+    f32x4 cs_v[CS_HOIST ? TN : 1];      // LN_A column sums: once per tile (see the GEGLU branch)
+    if (CS_HOIST) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = col0 + j * 16;
+            cs_v[j] = *reinterpret_cast<const f32x4*>(p.ln_colsum + (n < p.N ? n : 0));
+        }
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -256,7 +271,8 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             if (!wide && (!m_ok || n >= p.N)) continue;
             float o[4];
             f32x4 cs = zero4;
-            if (LNA) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
+            if (CS_HOIST) cs = cs_v[CS_HOIST ? j : 0];
+            else if (LNA) cs = *reinterpret_cast<const f32x4*>(p.ln_colsum + n);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = acc[i][j][r];
@@ -326,6 +342,198 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_rows_ln(const LbGemmParams
             f[2 * (long)(n + 1) * chst_ld + which] = red[1];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LEAN epilogue (round 5): the same arithmetic as above for the launches that carry the programs' time - fp16 row-major
+// output through the 16-byte stores, alpha, bias, and EITHER a time-embedding row vector OR an fp16 residual (optionally
+// the channel statistics of the halo convs) - with ONE memory round trip per tile and 32-bit addressing.
+//
+// Why.  vmcnt retires in order and counts stores as well as loads on gfx950, so a load issued after a store also waits
+// for that store's acknowledgement.  The general epilogue above loads a row's operands, waits, stores the row and goes on
+// to the next row: TM dependent (load + store-acknowledge) round trips per tile - 4-6 us per 256-pixel tile of the halo
+// conv (profiles/r02_halo_study.txt: a third of an 18-step Cin = 128 tile) and most of the ~13 us a 28 us projection GEMM
+// spends outside its K loop (M 4352, N 1280: K 1280 / 2560 / 5120 = 28.1 / 43.1 / 76.0 us, profiles/r04_gemm_bench_call2.txt).
+// Here every global load of the TILE is issued back to back before the first store (bias and row vector once per column
+// group - the row vector of a tile that lies inside one sample is the same for all of its rows -, the residual for all
+// TM x TN groups), and the stores then stream without a wait.  Operands are addressed as wave-uniform base pointer (SGPRs)
+// + 32-bit lane offset: one VGPR and no 64-bit multiplies per access, which is what lets the 254-register halo conv hold
+// the preloaded residual at all.  Same expressions, same order of the additions as the general form: bit-identical.
+// In-place residuals (residual == C) stay correct: a wave reads all of its tile before it writes any of it.
+//
+// Returns false (nothing done; the caller runs the general epilogue) for every other flag / shape combination.
+//   row_of(i)  logical row m of the lane's i-th 16-row group (row mask, residual row); row_of(i) >= row_lo
+//   row_lo     wave-uniform: smallest logical row of the wave tile; row_hi: one past its largest (row masks only if row_hi > M)
+//   out_rel(i) output row of row_of(i) minus out_lo (>= 0)      out_lo  wave-uniform origin of the output rows
+//   batch      wave-uniform sample index of the tile for the row vector, -1 = its rows may span samples
+//   colw       wave-uniform first column of the wave tile (the lane's quad of group j is colw + 16 j + 4 g)
+//   SCATTERED  the caller's out_rel already implements p.scatter (halo conv); otherwise p.scatter != 0 is declined
+// ------------------------------------------------------------------------------------------------
+// A wave-uniform GLOBAL pointer in scalar registers (readfirstlane of both halves; address space 1, so that accesses
+// through it are global_* instructions with the base in SGPRs and a 32-bit lane offset, not flat_* on a 64-bit VGPR pair).
+typedef __attribute__((address_space(1))) char lb_gchar;
+__device__ __forceinline__ lb_gchar* lb_uniform_ptr(const void* ptr) {
+    const unsigned long long v = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (lb_gchar*)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ T lb_gload(const lb_gchar* base, unsigned lane_off, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) T*>(base + (size_t)lane_off + imm);
+}
+template <typename T> __device__ __forceinline__ void lb_gstore(lb_gchar* base, unsigned lane_off, int imm, T v) {
+    *reinterpret_cast<__attribute__((address_space(1))) T*>(base + (size_t)lane_off + imm) = v;
+}
+
+template <int TM, int TN, bool CHST, bool MASKED, typename RowFn, typename OutFn>
+__device__ __forceinline__ void lb_gemm_tile_epilogue_lean_body(const LbGemmParams& p, const f32x4 (&acc)[TM][TN], RowFn row_of,
+                                                                int row_lo, OutFn out_rel, long out_lo, int batch, int colw,
+                                                                float2* chst, long chst_ld) {
+    typedef unsigned lb_u4w __attribute__((ext_vector_type(4)));
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // (the lane id goes through an opaque register: everything derived from it is tile-invariant, and inside the persistent
+    // halo conv the compiler would otherwise hoist those values out of the tile loop, hold them across the MFMA loop and spill)
+    int lane_ = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_));
+    const int g = lane_ >> 4;
+    const unsigned cq = 4u * g;                                             // the lane's quad inside a 16-column group
+    const unsigned sc = ((g & 1) ? 16u : 0u) + ((g & 2) ? 8u : 0u);         // its 8 stored columns of a group pair start here
+    const bool has_res = p.residual != nullptr;
+    lb_gchar* const cb = lb_uniform_ptr((f16*)p.C + out_lo * p.ldc + colw);
+    const lb_gchar* const rb = lb_uniform_ptr((const f16*)p.residual + (has_res ? (long)row_lo * p.ldr + colw : 0));
+    // ---- phase A: every global load of the tile ----
+    unsigned ro[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = row_of(i);
+        if (MASKED) m = m < p.M ? m : p.M - 1;                              // (row_lo < M: checked by the caller)
+        ro[i] = ((unsigned)(m - row_lo) * (unsigned)p.ldr + cq) * 2u;
+    }
+    f32x4 addv[TN];                                                         // bias (+ row vector) of the lane's column groups
+#pragma unroll
+    for (int j = 0; j < TN; ++j) addv[j] = zero4;
+    if (p.bias) {
+        const lb_gchar* const bb = lb_uniform_ptr(p.bias + colw);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) addv[j] = lb_gload<f32x4>(bb, cq * 4u, j * 64);
+    }
+    f16x4 rv[TN];
+    if (p.rowvec) {
+        const lb_gchar* const vb = lb_uniform_ptr(reinterpret_cast<const f16*>(p.rowvec) + (long)batch * p.ld_rowvec + colw);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rv[j] = lb_gload<f16x4>(vb, cq * 2u, j * 32);
+    }
+    f16x4 pre[TM][TN];
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) pre[i][j] = lb_gload<f16x4>(rb, ro[i], j * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);                                      // loads above; arithmetic and stores below
+    if (p.rowvec) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) addv[j][r] += (float)rv[j][r];
+    }
+    // a use of every loaded value on every path, here: the one wait of the epilogue (a value still "pending" at the end
+    // of a masked path would make the compiler drain vmcnt at the head of the persistent halo conv's MFMA loop)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(addv[j]));
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(pre[i][j]));
+    }
+    // ---- phase B: arithmetic and stores ----
+    float cs_s[CHST ? TN : 1][4], cs_q[CHST ? TN : 1][4];
+    if (CHST) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs_s[j][r] = cs_q[j][r] = 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const bool ok = !MASKED || row_of(i) < p.M;
+        const unsigned co = ((unsigned)out_rel(i) * (unsigned)p.ldc + sc) * 2u;
+        unsigned lo0 = 0u, lo1 = 0u;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 add = addv[j];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) add[r] += (float)pre[i][j][r];
+            }
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = acc[i][j][r];
+                o[r] = a * p.alpha + add[r];
+            }
+            const f16x4 h4 = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+            if (CHST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float h = (float)h4[r];                           // the value a GroupNorm pass would read back
+                    cs_s[j][r] += h;
+                    cs_q[j][r] += h * h;
+                }
+            }
+            const unsigned u0 = __builtin_bit_cast(unsigned, (lb_h2x){h4[0], h4[1]}), u1 = __builtin_bit_cast(unsigned, (lb_h2x){h4[2], h4[3]});
+            if ((j & 1) == 0) {
+                lo0 = u0;
+                lo1 = u1;
+            } else {            // (the exchange of the general epilogue's WIDE stores)
+                const auto r0 = __builtin_amdgcn_permlane16_swap(lo0, u0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(lo1, u1, false, false);
+                if (ok) lb_gstore<lb_u4w>(cb, co, (j >> 1) * 64, (lb_u4w){r0[0], r1[0], r0[1], r1[1]});
+            }
+        }
+    }
+    if constexpr (CHST) {
+        static_assert(TN == 4, "the channel-statistics epilogue folds 2 x 16 column values per lane");
+        float v[32], red[2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[j * 4 + r] = cs_s[j][r];
+                v[16 + j * 4 + r] = cs_q[j][r];
+            }
+        lb_row16_reduce32(v, red);
+        const int l = lane_ & 15;
+        const int which = l & 1, j = ((l >> 1) & 1) * 2 + ((l >> 2) & 1), r0 = (l >> 3) * 2;     // the two values this lane holds
+        const int n = colw + 4 * g + j * 16 + r0;
+        float* f = reinterpret_cast<float*>(chst);            // chst = &stats[0][row block]; channel n lives chst_ld float2 further on
+        f[2 * (long)n * chst_ld + which] = red[0];
+        f[2 * (long)(n + 1) * chst_ld + which] = red[1];
+    }
+}
+
+template <int TM, int TN, bool CHST, bool SCATTERED, typename RowFn, typename OutFn>
+__device__ __forceinline__ bool lb_gemm_tile_epilogue_lean(const LbGemmParams& p, const f32x4 (&acc)[TM][TN], RowFn row_of, int row_lo_,
+                                                           int row_hi_, OutFn out_rel, long out_lo_, int batch_, int colw_,
+                                                           float2* chst = nullptr, long chst_ld = 1) {
+    static_assert(TN % 2 == 0, "the lean epilogue stores column-group pairs");
+    // (wave-uniform by contract; through readfirstlane so that the compiler keeps them - and the branches below - scalar)
+    const int row_lo = __builtin_amdgcn_readfirstlane(row_lo_), row_hi = __builtin_amdgcn_readfirstlane(row_hi_);
+    const int batch = __builtin_amdgcn_readfirstlane(batch_), colw = __builtin_amdgcn_readfirstlane(colw_);
+    const long out_lo = (long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)out_lo_ >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)out_lo_));
+    constexpr int UNSUPPORTED = LB_GEMM_TRANS_OUT | LB_GEMM_OUT_F32 | LB_GEMM_SILU | LB_GEMM_RELU | LB_GEMM_QUICK_GELU | LB_GEMM_GELU |
+                                LB_GEMM_RES_F32 | LB_GEMM_GEGLU | LB_GEMM_LN_A;
+    const bool eligible = !(p.flags & UNSUPPORTED) && (p.reserved2_ & 3) == 3 && (p.ldc & 7) == 0 && (p.ldr & 3) == 0 && colw + 16 * TN <= p.N &&
+                          (SCATTERED || p.scatter == 0) && !(p.rowvec != nullptr && (p.residual != nullptr || batch < 0)) &&
+                          (CHST || !(p.flags & LB_GEMM_CH_STATS));
+    if (!eligible) return false;
+    if (row_lo >= p.M) return true;                             // (a wave tile entirely below the last row)
+    if (row_hi <= p.M)
+        lb_gemm_tile_epilogue_lean_body<TM, TN, CHST, false>(p, acc, row_of, row_lo, out_rel, out_lo, batch, colw, chst, chst_ld);
+    else
+        lb_gemm_tile_epilogue_lean_body<TM, TN, CHST, true>(p, acc, row_of, row_lo, out_rel, out_lo, batch, colw, chst, chst_ld);
+    return true;
 }
 
 template <int TM, int TN, bool GEGLU, typename RowFn>

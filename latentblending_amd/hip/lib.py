@@ -70,6 +70,7 @@ SIGNATURES = {
     "lb_gemm_set_depth": (None, [_i]),
     "lb_gemm_set_variant": (None, [_i, _i]),
     "lb_gemm_set_wide_store": (None, [_i]),
+    "lb_gemm_set_lean_epilogue": (None, [_i]),
     "lb_gemm_pp_set_group": (None, [_i]),
     "lb_gemm_set_pp_auto": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
@@ -125,7 +126,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_set_lean_epilogue", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 
@@ -171,5 +172,7 @@ for _name, (_res, _args) in STUDY_SIGNATURES.items():
 
 if os.environ.get("LB_GEMM_WIDE_STORE"):        # tuning experiments (tools/): 16-byte epilogue stores
     api.lb_gemm_set_wide_store(int(os.environ["LB_GEMM_WIDE_STORE"]))
+if os.environ.get("LB_GEMM_LEAN_EPILOGUE"):     # A/B studies (tools/): 0 = the per-row tile epilogue everywhere
+    api.lb_gemm_set_lean_epilogue(int(os.environ["LB_GEMM_LEAN_EPILOGUE"]))
 if os.environ.get("LB_GEMM_PP_AUTO"):           # A/B studies (tools/): 0 = the tile policy never picks the ping-pong GEMM
     api.lb_gemm_set_pp_auto(int(os.environ["LB_GEMM_PP_AUTO"]))

@@ -848,3 +848,106 @@ def test_gemm_pingpong_geglu_and_splitk(results_log):
         check_close(results_log, "pp_splitk3", got, A.float() @ W.float().t())
     finally:
         l.api.lb_gemm_set_tuning(0, 0)
+
+
+# ------------------------------------------------------------------ one-round-trip tile epilogue (lb_gemm.h, round 5)
+def _lean_ab(fn):
+    """fn() with the per-row epilogue everywhere, then with the one-round-trip form: both results."""
+    l = lib()
+    l.api.lb_gemm_set_lean_epilogue(0)
+    try:
+        a = fn()
+    finally:
+        l.api.lb_gemm_set_lean_epilogue(1)
+    return a, fn()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 9])
+@pytest.mark.parametrize("shape", [(4352, 1280, 640), (1000, 384, 256), (300, 260, 128), (512, 768, 192)])
+def test_lean_epilogue_gemm_bit_identical(shape, tile, results_log):
+    """Every tile family, whole and ragged wave tiles (M = 1000 / 300: masked rows; N = 260 / 384: wave tiles that overhang N fall back
+    to the general form), alpha, bias, fp16 residual - also IN PLACE (residual == output), and a time-embedding row vector whose
+    samples are 250 rows long (wave tiles inside one sample take the lean form, tiles across a boundary the general one): the
+    stored bits must not depend on the epilogue form, and must match the fp32 reference."""
+    o, l = ops(), lib()
+    M, N, K = shape
+    A, W = rnd(M, K, seed=301).to(DEV), rnd(N, K, seed=302, scale=K ** -0.5).to(DEV)
+    bias, res = rnd(N, seed=303, dtype=torch.float32).to(DEV), rnd(M, N, seed=304).to(DEV)
+    rpb = 250 if M % 250 == 0 else M // 4
+    rv = rnd(M // rpb, N, seed=305).to(DEV)
+    l.api.lb_gemm_set_tuning(tile, 1 if tile else 0)
+    try:
+        a, b = _lean_ab(lambda: o.gemm(A, W, bias=bias, residual=res, alpha=0.5))
+        assert torch.equal(a, b)
+        check_close(results_log, f"lean_epi_gemm_{M}x{N}x{K}_t{tile}", b, 0.5 * (A.float() @ W.float().t()) + bias + res.float())
+        a, b = _lean_ab(lambda: o.gemm(A, W, bias=bias, rowvec=rv, rows_per_batch=rpb))
+        assert torch.equal(a, b)
+        check_close(results_log, f"lean_epi_gemm_rowvec_{M}x{N}x{K}_t{tile}", b,
+                    A.float() @ W.float().t() + bias + rv.float().repeat_interleave(rpb, 0))
+        a, b = _lean_ab(lambda: o.gemm(A, W))
+        assert torch.equal(a, b)
+
+        def in_place():
+            buf = res.clone()
+            o.gemm(A, W, bias=bias, residual=buf, out=buf)
+            return buf
+        a, b = _lean_ab(in_place)
+        assert torch.equal(a, b)
+        assert torch.equal(b, o.gemm(A, W, bias=bias, residual=res))
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 128, 32), (1, 64, 64, 128, 320, 32), (3, 16, 16, 192, 132, 16), (2, 48, 16, 128, 256, 16)])
+def test_lean_epilogue_halo_conv_bit_identical(case, results_log):
+    """The persistent halo conv (TW = 32 and 16, several tiles per block, N = 132 / 320: a last channel block that overhangs N takes
+    the general form) with bias + residual, bias + time-embedding vector, alpha, and the channel statistics: same stored bits and
+    same statistics under both epilogue forms."""
+    o, l = ops(), lib()
+    B, H, Wd, Cin, Cout, tw = case
+    x = rnd(B, H, Wd, Cin, seed=311).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=312, scale=(Cin * 9) ** -0.5)
+    wp = o.pack_conv_weight(w, Cin).to(DEV)
+    b = rnd(Cout, seed=313, dtype=torch.float32).to(DEV)
+    res, temb = rnd(B, H, Wd, Cout, seed=314).to(DEV), rnd(B, Cout, seed=315).to(DEV)
+    conv = dict(KH=3, KW=3, stride=1, pad=1, halo=True)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w.float(), b.cpu(), padding=1).permute(0, 2, 3, 1)
+    a, c = _lean_ab(lambda: o.gemm(x, wp, bias=b, residual=res, alpha=0.25, conv=conv))
+    assert torch.equal(a, c)
+    check_close(results_log, f"lean_epi_halo_res_{'_'.join(map(str, case))}", c, 0.25 * (ref - b.cpu()) + b.cpu() + res.float().cpu())
+    a, c = _lean_ab(lambda: o.gemm(x, wp, bias=b, rowvec=temb, rows_per_batch=H * Wd, conv=conv))
+    assert torch.equal(a, c)
+    check_close(results_log, f"lean_epi_halo_temb_{'_'.join(map(str, case))}", c, ref + temb.float().cpu()[:, None, None, :])
+    if Cout % 128 == 0:
+        l.api.lb_gemm_set_halo(2)
+        try:
+            rows = o.conv_ch_stat_rows(B, H, Wd, Cin, Cout)
+
+            def with_stats():
+                st = torch.full((Cout, B * rows, 2), float("nan"), dtype=torch.float32, device=DEV)
+                y = o.gemm(x, wp, bias=b, residual=res, conv=dict(KH=3, KW=3, stride=1, pad=1), ch_stats=st)
+                return torch.cat([y.float().reshape(-1), st.reshape(-1)])
+            a, c = _lean_ab(with_stats)
+        finally:
+            l.api.lb_gemm_set_halo(1)
+        assert torch.isfinite(c).all() and torch.equal(a, c)
+
+
+@pytest.mark.parametrize("B,H,Wd,Cin,Cout", [(2, 16, 32, 64, 128), (1, 32, 32, 128, 256), (2, 16, 16, 64, 200)])
+def test_lean_epilogue_subpixel_upconv_bit_identical(B, H, Wd, Cin, Cout, results_log):
+    """The 2x2 sub-pixel form (all four parities in one launch): the lean epilogue computes the scattered output rows itself."""
+    o = ops()
+    x, w = rnd(B, Cin, H, Wd, seed=321), rnd(Cout, Cin, 3, 3, seed=322, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=323, dtype=torch.float32).to(DEV)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias.cpu(), padding=1).permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    subs = o.subpixel_upsample_weights(w)
+    w4 = torch.stack([subs[(0, 0)], subs[(0, 1)], subs[(1, 0)], subs[(1, 1)]]).to(DEV).contiguous()
+
+    def run():
+        out = torch.full((B, 2 * H, 2 * Wd, Cout), float("nan"), dtype=torch.float16, device=DEV)
+        o.gemm(xn, w4[0], bias=bias, out=out, alpha=0.5, conv=dict(KH=2, KW=2, stride=1, pad=0, parity="all"))
+        return out
+    a, c = _lean_ab(run)
+    assert torch.isfinite(c).all() and torch.equal(a, c)
+    check_close(results_log, f"lean_epi_upconv_{B}x{H}x{Wd}x{Cin}x{Cout}", c, 0.5 * (ref - bias.cpu()) + bias.cpu(), rel=3e-3)

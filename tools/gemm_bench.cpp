@@ -68,7 +68,7 @@ static void fill_half(std::vector<__half>& v, float scale) {
     for (auto& x : v) x = __float2half(frand() * scale);
 }
 
-struct Variant { const char* name; int tile; int splitk; int group; };
+struct Variant { const char* name; int tile; int splitk; int group; int lean = 1; };    // lean: lb_gemm_set_lean_epilogue
 
 int main(int argc, char** argv) {
     const std::string set = argc > 1 ? argv[1] : "b17";
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     if (set == "b17" || set == "all") shapes.insert(shapes.end(), std::begin(B17), std::end(B17));
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
-    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t1", 1, 1, 8}};
+    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t1", 1, 1, 8}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
     {
@@ -146,6 +146,7 @@ int main(int argc, char** argv) {
         auto run = [&](const Variant& v, int wi, __half* out) {
             lb_gemm_set_tuning(v.tile, v.splitk);
             lb_gemm_pp_set_group(v.group);
+            lb_gemm_set_lean_epilogue(v.lean);
             LbGemmParams p = params(wi, out);
             const int rc = lb_gemm_f16(&p, stream);
             if (rc) { fprintf(stderr, "lb_gemm_f16 failed: %s\n", lb_last_error_string()); exit(3); }
