@@ -65,6 +65,12 @@ int lb_scale_model_input_f16(const void* x, void* out, const float* params_dev, 
 int lb_euler_step_f16(const void* x, const void* eps, const void* noise, void* out,
                       const float* params_dev, long per_sample, int batch, int cfg, int ancestral,
                       void* stream);
+/* diffusers DDIMScheduler.step, eta = 0, epsilon prediction (diffusers_holder.py:356 with a DDIM scheduler on the pipe; the
+ * reference's SDXL pipes carry Euler schedulers, :42).  params_dev: float[batch][8] = {0, sqrt(abar_t), sqrt(abar_prev),
+ * guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), -, -} - slot 0 = 0 makes lb_scale_model_input_f16 the identity, as DDIM's
+ * scale_model_input is.  fp16 tensor arithmetic rounded op by op like diffusers' (no fp32 upcast in DDIM).  eps as above. */
+int lb_ddim_step_f16(const void* x, const void* eps, void* out, const float* params_dev, long per_sample, int batch,
+                     int cfg, void* stream);
 
 /* ---- dense contractions (every nn.Linear / nn.Conv2d of the UNet at
  *      diffusers_holder.py:336, of the VAE decoder at :135 and of LPIPS-Alex at

@@ -965,9 +965,13 @@ class BlendingEngine:
                 setattr(self, name, float(state[name]))
         if 'guidance_scale_base' in state or 'guidance_scale' in state:
             self.set_guidance_scale(float(state.get('guidance_scale_base', state.get('guidance_scale'))))
-        if state.get('negative_prompt') is not None:
-            neg = state['negative_prompt']
-            self.set_negative_prompt(neg if isinstance(neg, str) else list(neg))
+        if 'negative_prompt' in state:          # (always applied when stored - also None: an engine / session that already has a
+            neg = state['negative_prompt']      # negative prompt must not keep it and re-embed the prompts under it)
+            if neg is None:                     # never set when the state was taken: the holder's default "" (diffusers_holder.py:23)
+                self.negative_prompt = None
+                self.dh.negative_prompt = ""
+            else:
+                self.set_negative_prompt(neg if isinstance(neg, str) else list(neg))
         if 'prompt1' in state:
             self.set_prompt1(state['prompt1'])
         if 'prompt2' in state:

@@ -506,6 +506,11 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         if (splitk > k_tiles) splitk = k_tiles;
         if (splitk < 1) splitk = 1;
         if (tile == 9 && !g_force_splitk) splitk = 1;         // (the policy takes the ping-pong kernel only for chip-filling grids)
+        // 6- / 8-wave tiles are only chosen for grids that already cover >= 62 % of the chip: their fp32 slabs (M x N x 4 B per slice,
+        // written and read back) outweigh the operands.  Measured (profiles/r05_gemm_bench_call2.txt): M 4352, N 1280, K 2560 / 5120 on
+        // the 256x128 tile = 39.1 / 75.1 us unsplit against 57.6 / 96.5 us with the 2 / 4 slices the "<= 256 blocks" rule above gave
+        // them (120 such launches per transition).  The rule is meant for the 4-wave tiles of the M = 256..1024 programs.
+        if (tile >= 4 && !g_force_splitk) splitk = 1;
     }
     tile_out = tile;
     splitk_out = splitk;

@@ -327,6 +327,7 @@ extern "C" void lb_gemm_pp_set_group(int gm) { g_pp_group = gm; }
 
 int lb_gemm_pp_eligible(const LbGemmParams& p) {
     return !p.conv && p.K % PP_BK == 0 && !(p.flags & (LB_GEMM_LN_A | LB_GEMM_CH_STATS)) && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
+           ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.W)) & 15) == 0 &&        // 16-byte LDS-DMA requests
            (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);       // 32-bit row offsets
 }
 

@@ -46,13 +46,12 @@ static inline int lb_check_launch(const char* what) {
 
 // "Once per DEVICE" guard for per-kernel attributes (hipFuncSetAttribute applies to the current device only: a process
 // that drives several GPUs must set it on each).  `seen` is the call site's own static bit mask (<= 64 devices).
+// (atomic test-and-set: two host threads recording programs at once must not both - or neither - see "first")
 static inline bool lb_first_call_on_device(unsigned long long& seen) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    if (seen & bit) return false;
-    seen |= bit;
-    return true;
+    return (__atomic_fetch_or(&seen, bit, __ATOMIC_ACQ_REL) & bit) == 0;
 }
 
 #define LB_REQUIRE(cond, what)                                   \

@@ -472,6 +472,9 @@ __device__ __forceinline__ void lb_gemm_tile_epilogue_lean_body(const LbGemmPara
                 const float a = acc[i][j][r];
                 o[r] = a * p.alpha + add[r];
             }
+            // (the fp32 result goes through an opaque register: hipcc would otherwise fuse "fma, then round to fp16" into
+            // v_fma_mix{lo,hi}_f16, which rounds ONCE - measured: not the bits of the general form's v_pk_fma_f32 + v_cvt)
+            asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
             const f16x4 h4 = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
             if (CHST) {
 #pragma unroll

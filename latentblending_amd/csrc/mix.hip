@@ -548,3 +548,73 @@ extern "C" int lb_euler_step_f16(const void* x, const void* eps, const void* noi
                      if (vec) euler_launch<true>(x, eps, noise, out, params_dev, per_sample, batch, cfg, ancestral, s);
                      else euler_launch<false>(x, eps, noise, out, params_dev, per_sample, batch, cfg, ancestral, s));
 }
+
+// ------------------------------------------------------------------------------------------------
+// DDIM step (eta = 0, epsilon prediction; diffusers DDIMScheduler.step as SD / SDXL configure it: clip_sample = False,
+// set_alpha_to_one = False, leading spacing with steps_offset = 1).  Third party, reached from
+// /root/reference/latentblending/diffusers_holder.py:356 when the pipe carries a DDIM scheduler (the reference's own SDXL
+// path constructs Euler schedulers, :42; north_star names "the Euler/DDIM step").
+//   params row: {0 (sigma of lb_scale_model_input_f16: DDIM's scale_model_input is the identity, x / sqrt(0 + 1) = x),
+//                sqrt(abar_t), sqrt(abar_prev), guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), -, -}
+// diffusers does NOT upcast here (Euler does): sample and model_output are fp16 tensors, the coefficients 0-dim fp32 tensors,
+// so EVERY tensor operation rounds to fp16 -
+//   x0   = (sample - sqrt(1 - abar_t) * eps) / sqrt(abar_t)          [mul, sub, true division: three roundings]
+//   dir  = sqrt(1 - abar_prev) * eps                                 [one]
+//   prev = sqrt(abar_prev) * x0 + dir                                [mul, add: two]
+// and this kernel rounds in the same six places (CFG combine as in euler_one).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f16 ddim_one(f16 xh, f16 eu, f16 et, float sa_t, float sa_p, float sb_t, float sb_p, float g, bool cfg) {
+    f16 e = eu;
+    if (cfg) {
+        const f16 diff = (f16)((float)et - (float)eu);
+        const f16 sc = (f16)(g * (float)diff);
+        e = (f16)((float)eu + (float)sc);
+    }
+    const f16 t1 = (f16)__fmul_rn(sb_t, (float)e);
+    const f16 t2 = (f16)__fsub_rn((float)xh, (float)t1);
+    const f16 x0 = (f16)__fdiv_rn((float)t2, sa_t);
+    const f16 dir = (f16)__fmul_rn(sb_p, (float)e);
+    const f16 t3 = (f16)__fmul_rn(sa_p, (float)x0);
+    return (f16)__fadd_rn((float)t3, (float)dir);
+}
+
+template <bool VEC, bool CFG>
+__global__ void __launch_bounds__(256) ddim_step_kernel(const f16* __restrict__ x, const f16* __restrict__ eps, f16* __restrict__ out,
+                                                         const float* __restrict__ params, long per_sample, int batch) {
+    const long total = per_sample * batch;
+    for (int b = blockIdx.y; b < batch; b += gridDim.y) {
+        const float sa_t = params[b * LB_STEP_STRIDE + 1], sa_p = params[b * LB_STEP_STRIDE + 2], g = params[b * LB_STEP_STRIDE + 3];
+        const float sb_t = params[b * LB_STEP_STRIDE + 4], sb_p = params[b * LB_STEP_STRIDE + 5];
+        const long base = (long)b * per_sample;
+        const long nvec = VEC ? per_sample >> 3 : 0;
+        const long stride = (long)gridDim.x * blockDim.x;
+        const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+            const long o = base + i * 8;
+            const f16x8 xv = *reinterpret_cast<const f16x8*>(x + o);
+            const f16x8 eu = *reinterpret_cast<const f16x8*>(eps + o);
+            const f16x8 et = CFG ? *reinterpret_cast<const f16x8*>(eps + total + o) : zero8;
+            f16x8 r;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = ddim_one(xv[j], eu[j], et[j], sa_t, sa_p, sb_t, sb_p, g, CFG);
+            *reinterpret_cast<f16x8*>(out + o) = r;
+        }
+        for (long i = (nvec << 3) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+            const long o = base + i;
+            out[o] = ddim_one(x[o], eps[o], CFG ? eps[o + total] : (f16)0.f, sa_t, sa_p, sb_t, sb_p, g, CFG);
+        }
+    }
+}
+
+extern "C" int lb_ddim_step_f16(const void* x, const void* eps, void* out, const float* params_dev, long per_sample, int batch,
+                                int cfg, void* stream) {
+    LB_REQUIRE(per_sample > 0 && batch > 0, "lb_ddim_step_f16: sizes");
+    const bool vec = per_sample % 8 == 0 && aligned16(x) && aligned16(eps) && aligned16(out);
+    const dim3 grid = sample_grid(per_sample, batch), block(256);
+#define LB_DDIM(V, C) hipLaunchKernelGGL((ddim_step_kernel<V, C>), grid, block, 0, s, (const f16*)x, (const f16*)eps, (f16*)out, params_dev, per_sample, batch)
+    LB_DISPATCH_STMT("lb_ddim_step_f16",
+                     if (vec && cfg) LB_DDIM(true, true); else if (vec) LB_DDIM(true, false);
+                     else if (cfg) LB_DDIM(false, true); else LB_DDIM(false, false));
+#undef LB_DDIM
+}
+

@@ -64,6 +64,7 @@ SIGNATURES = {
     "lb_lerp_f32": (_i, [_vp, _vp, _vp, _l, _d, _vp]),
     "lb_scale_model_input_f16": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "lb_euler_step_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "lb_ddim_step_f16": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "lb_gemm_f16": (_i, [C.POINTER(LbGemmParams), _vp]),
     "lb_gemm_workspace_bytes": (_l, [_i, _i]),
     "lb_gemm_set_tuning": (None, [_i, _i]),

@@ -112,6 +112,14 @@ def euler_step(x, eps, params, noise=None, cfg=False, ancestral=False) -> torch.
     return out
 
 
+def ddim_step(x, eps, params, cfg=False) -> torch.Tensor:
+    """DDIM step (eta = 0); ``params`` rows as NativeDDIMScheduler.step_row builds them."""
+    out = torch.empty_like(x)
+    api.lb_ddim_step_f16(x.data_ptr(), eps.data_ptr(), out.data_ptr(), params.data_ptr(), x[0].numel(), x.shape[0], int(cfg),
+                         stream_ptr())
+    return out
+
+
 # ------------------------------------------------------------------------------ GEMM / conv
 def pack_linear_weight(w: torch.Tensor) -> torch.Tensor:
     """[N, K] -> fp16 [N, K] contiguous (K padded to a multiple of 8 with zeros)."""

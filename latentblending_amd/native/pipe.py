@@ -35,7 +35,7 @@ from ..hip import ops
 from ..hip.lib import api
 from .frames import DeviceImage
 from .lpips import NativeLPIPS
-from .scheduler import NativeEulerScheduler
+from .scheduler import NativeDDIMScheduler, NativeEulerScheduler
 from .unet import NativeUNet, UNetConfig, UNetProgram
 from .vae import NativeVAEDecoder, VAEConfig, VAEProgram
 from .weights import SyntheticProvider
@@ -103,8 +103,11 @@ class StableDiffusionXLPipeline:
                  vae_cfg: Optional[VAEConfig] = None, unet_provider=None, vae_provider=None,
                  lpips_provider=None, device="cuda", seed: int = 0, name_or_path: Optional[str] = None,
                  text_encoder_fn=None, unet_native: Optional[NativeUNet] = None,
-                 vae_native: Optional[NativeVAEDecoder] = None, allow_synthetic: Optional[bool] = None):
-        """``allow_synthetic``: seeded synthetic stand-ins (UNet / VAE / LPIPS weights when no provider is given,
+                 vae_native: Optional[NativeVAEDecoder] = None, allow_synthetic: Optional[bool] = None,
+                 scheduler: Optional[str] = None):
+        """``scheduler``: None = the reference pipes' choice (Euler-ancestral for Turbo, Euler for base); "ddim" = diffusers'
+        DDIMScheduler (eta 0) behind the same native loops.
+        ``allow_synthetic``: seeded synthetic stand-ins (UNet / VAE / LPIPS weights when no provider is given,
         prompt embeddings when no ``text_encoder_fn`` is given) are used silently when True (tests, bench: also
         ``LB_ALLOW_SYNTHETIC=1``); otherwise each stand-in announces itself ONCE with a ``UserWarning`` - frames
         rendered from them are noise-like and prompts have no semantic effect."""
@@ -130,7 +133,8 @@ class StableDiffusionXLPipeline:
         self.unet_native = unet_native or NativeUNet(self.unet_cfg, unet_provider or SyntheticProvider(seed), self.device)
         self.vae_native = vae_native or NativeVAEDecoder(self.vae_cfg, vae_provider or SyntheticProvider(seed + 1), self.device)
         self.lpips_metric = NativeLPIPS(lpips_provider or SyntheticProvider(7), self.device)
-        self.scheduler = NativeEulerScheduler(ancestral=turbo, device=self.device)
+        # (the reference's SDXL pipes carry Euler / Euler-ancestral schedulers; scheduler="ddim" = diffusers' DDIMScheduler, eta 0)
+        self.scheduler = NativeDDIMScheduler(device=self.device) if scheduler == "ddim" else NativeEulerScheduler(ancestral=turbo, device=self.device)
         self.unet = _UNetFacade(self)
         self.vae = _VAEFacade(self)
         self.image_processor = _ImageProcessor()
@@ -379,7 +383,7 @@ class StableDiffusionXLPipeline:
             self.stats["unet_forwards"] += 1
             self.stats["unet_samples"] += prog.B
             noise = noise_all[i - idx_start] if noise_all is not None else None
-            latents = ops.euler_step(latents, prog.eps, params, noise=noise, cfg=cfg, ancestral=sched.ancestral)
+            latents = sched.device_step(latents, prog.eps, params, noise=noise, cfg=cfg)
             for g in range(G):
                 trajs[g].append(latents[g:g + 1])
         return trajs
@@ -437,32 +441,39 @@ class StableDiffusionXLPipeline:
             neg_pool = torch.cat([c[3] for c in conds]).to(self.device, F16)
             return torch.cat([neg_ctx, pos_ctx]), torch.cat([neg_pool, pos_pool])
 
-        def prepared(conds):
+        def prepared(conds, side=None):
+            # (the program - arena, workspaces, first-time graph instantiation - is always obtained on the MAIN stream: its
+            # allocations then belong to the main stream's allocator pool; only the conditioning launches move to `side`)
             prog = self.unet_program(len(conds) * mul, L)
-            ctx, pooled = conditioning(conds)
-            ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
-            prog.set_conditioning(ctx, pooled, ids)
-            return prog
+            if side is None:
+                ctx, pooled = conditioning(conds)
+                ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
+                prog.set_conditioning(ctx, pooled, ids)
+                return prog, None
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ctx, pooled = conditioning(conds)
+                ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
+                prog.set_conditioning(ctx, pooled, ids)
+                for t in (ctx, pooled, ids):    # (allocated on the side stream, read by launches of the main stream later)
+                    t.record_stream(torch.cuda.current_stream())
+                return prog, side.record_event()
 
         # G == 0: a farm rank that owns no mid branch of the round (fewer gaps than ranks) still runs both anchors
         dead = [bool(elide_dead_steps) and G > 0 and i >= idx_injection and i + 1 < steps and
                 all(float(mid_coeffs[g][i + 1]) == 1.0 for g in range(G)) for i in range(steps)]
-        prog_a = prepared(list(anchor_conds)) if A and (idx_injection > 0 or G == 0 or any(dead)) else None
+        prog_a = prepared(list(anchor_conds))[0] if A and (idx_injection > 0 or G == 0 or any(dead)) else None
         # The big batch's conditioning program (every branch's context K | V projection: ~1.1 ms at 17 samples) does not depend
         # on any latent: when small anchor-only steps come first it runs on a SIDE stream beside them (they leave most of the
         # chip idle) and the main stream waits for it only before the first big step.  Different programs own different
         # arenas / workspaces, so the two streams share nothing but read-only weights.
         cond_ready = None
         if G and prog_a is not None and idx_injection > 0:
-            main = torch.cuda.current_stream()
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
-            self._side_stream.wait_stream(main)
-            with torch.cuda.stream(self._side_stream):
-                prog_all = prepared(list(anchor_conds) + list(mid_conds))
-                cond_ready = self._side_stream.record_event()
+            prog_all, cond_ready = prepared(list(anchor_conds) + list(mid_conds), side=self._side_stream)
         else:
-            prog_all = prepared(list(anchor_conds) + list(mid_conds)) if G else prog_a
+            prog_all = prepared(list(anchor_conds) + list(mid_conds))[0] if G else prog_a
         stream = torch.cuda.current_stream().cuda_stream
         rows_a = [sched.step_row(i, all_g[0]) for i in range(steps)]
         par_a = ops.step_params([r for r in rows_a for _ in range(A)], self.device).view(steps, A, 8) if A else None
@@ -489,58 +500,62 @@ class StableDiffusionXLPipeline:
         fr_dev = torch.tensor([float(f) for f in mid_fracts], dtype=torch.float64, device=self.device) if G else None
         coef_dev = torch.tensor([[float(mid_coeffs[g][i]) for g in range(G)] for i in range(steps)],
                                 dtype=torch.float64, device=self.device) if G else None
-        for i in range(steps):
-            if i < idx_injection or G == 0 or dead[i]:
-                if dead[i] and i == idx_injection:
-                    # the mids' (never denoised) start value: the parental mix of step i-1, exactly what the live path starts
-                    # from - the next step's crossfeed slerp at coefficient 1.0 replaces it bit for bit, but its FIRST operand
-                    # must be a proper latent (a zero tensor has no direction: 0 / 0 in the slerp's cosine)
-                    lat_m = ops.slerp_strided(traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous(), fr_dev, n_lat,
-                                              broadcast0=True, broadcast1=True).view(G, *lat_shape)
+        try:
+            for i in range(steps):
+                if i < idx_injection or G == 0 or dead[i]:
+                    if dead[i] and i == idx_injection:
+                        # the mids' (never denoised) start value: the parental mix of step i-1, exactly what the live path starts
+                        # from - the next step's crossfeed slerp at coefficient 1.0 replaces it bit for bit, but its FIRST operand
+                        # must be a proper latent (a zero tensor has no direction: 0 / 0 in the slerp's cosine)
+                        lat_m = ops.slerp_strided(traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous(), fr_dev, n_lat,
+                                                  broadcast0=True, broadcast1=True).view(G, *lat_shape)
+                        self.stats["slerps"] += G
+                    if A == 0:                  # both anchors known: nothing runs before the injection step (or in a dead one)
+                        if i >= idx_injection and G and dead[i]:
+                            for g in range(G):
+                                traj_m[g].append(None)
+                        continue
+                    prog, lat, params, n = prog_a, lat_a, par_a[i], A
+                    noise = noise_a[i] if noise_a is not None else None
+                else:
+                    prev1, prev2 = traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous()
+                    mix_prev = ops.slerp_strided(prev1, prev2, fr_dev, n_lat, broadcast0=True, broadcast1=True)   # parental mix of step i-1
                     self.stats["slerps"] += G
-                if A == 0:                  # both anchors known: nothing runs before the injection step (or in a dead one)
-                    if i >= idx_injection and G and dead[i]:
-                        for g in range(G):
-                            traj_m[g].append(None)
-                    continue
-                prog, lat, params, n = prog_a, lat_a, par_a[i], A
-                noise = noise_a[i] if noise_a is not None else None
-            else:
-                prev1, prev2 = traj_a[0][i - 1].contiguous(), traj_a[1][i - 1].contiguous()
-                mix_prev = ops.slerp_strided(prev1, prev2, fr_dev, n_lat, broadcast0=True, broadcast1=True)   # parental mix of step i-1
-                self.stats["slerps"] += G
-                if i == idx_injection:
-                    lat_m = mix_prev.view(G, *lat_shape)
-                elif dead[i - 1]:
-                    assert all(float(mid_coeffs[g][i]) == 1.0 for g in range(G))
-                nfeed = sum(1 for g in range(G) if mid_coeffs[g][i] > 0)
-                if nfeed:       # (a coefficient of 0 returns the first operand bit-exactly, like the reference's skipped slerp)
-                    lat_m = ops.slerp_strided(lat_m.contiguous().view(G, n_lat), mix_prev, coef_dev[i], n_lat).view(G, *lat_shape)
-                    self.stats["slerps"] += nfeed
-                prog, lat, params, n = prog_all, (torch.cat([lat_a, lat_m]) if A else lat_m.contiguous()), par_all[i - idx_injection], A + G
-                if cond_ready is not None:
-                    torch.cuda.current_stream().wait_event(cond_ready)
-                    cond_ready = None
-                noise = None
-                if noise_m is not None:
-                    noise = torch.cat([noise_a[i], noise_m[i - idx_injection]]) if A else noise_m[i - idx_injection]
-            api.lb_scale_model_input_f16(lat.data_ptr(), prog.x_in.data_ptr(), params.data_ptr(), per_sample, n,
-                                         int(cfg), stream)
-            prog.tvals.fill_(float(sched.timesteps_np[i]))
-            prog.prog_step.launch(stream)
-            self.stats["unet_forwards"] += 1
-            self.stats["unet_samples"] += prog.B
-            out = ops.euler_step(lat, prog.eps, params, noise=noise, cfg=cfg, ancestral=sched.ancestral)
-            lat_a = out[:A]
-            for j, k in enumerate(live):
-                traj_a[k].append(out[j:j + 1])
-            if i >= idx_injection and G and dead[i]:
-                for g in range(G):
-                    traj_m[g].append(None)
-            elif i >= idx_injection and G:
-                lat_m = out[A:]
-                for g in range(G):
-                    traj_m[g].append(out[A + g:A + g + 1])
+                    if i == idx_injection:
+                        lat_m = mix_prev.view(G, *lat_shape)
+                    elif dead[i - 1]:
+                        assert all(float(mid_coeffs[g][i]) == 1.0 for g in range(G))
+                    nfeed = sum(1 for g in range(G) if mid_coeffs[g][i] > 0)
+                    if nfeed:       # (a coefficient of 0 returns the first operand bit-exactly, like the reference's skipped slerp)
+                        lat_m = ops.slerp_strided(lat_m.contiguous().view(G, n_lat), mix_prev, coef_dev[i], n_lat).view(G, *lat_shape)
+                        self.stats["slerps"] += nfeed
+                    prog, lat, params, n = prog_all, (torch.cat([lat_a, lat_m]) if A else lat_m.contiguous()), par_all[i - idx_injection], A + G
+                    if cond_ready is not None:
+                        torch.cuda.current_stream().wait_event(cond_ready)
+                        cond_ready = None
+                    noise = None
+                    if noise_m is not None:
+                        noise = torch.cat([noise_a[i], noise_m[i - idx_injection]]) if A else noise_m[i - idx_injection]
+                api.lb_scale_model_input_f16(lat.data_ptr(), prog.x_in.data_ptr(), params.data_ptr(), per_sample, n,
+                                             int(cfg), stream)
+                prog.tvals.fill_(float(sched.timesteps_np[i]))
+                prog.prog_step.launch(stream)
+                self.stats["unet_forwards"] += 1
+                self.stats["unet_samples"] += prog.B
+                out = sched.device_step(lat, prog.eps, params, noise=noise, cfg=cfg)
+                lat_a = out[:A]
+                for j, k in enumerate(live):
+                    traj_a[k].append(out[j:j + 1])
+                if i >= idx_injection and G and dead[i]:
+                    for g in range(G):
+                        traj_m[g].append(None)
+                elif i >= idx_injection and G:
+                    lat_m = out[A:]
+                    for g in range(G):
+                        traj_m[g].append(out[A + g:A + g + 1])
+        finally:
+            if cond_ready is not None:      # (an exception before the first big step: never leave the side stream's conditioning
+                torch.cuda.current_stream().wait_event(cond_ready)    # launches un-joined - a later call reuses the cached program)
         return traj_a[0], traj_a[1], traj_m
 
     @torch.no_grad()

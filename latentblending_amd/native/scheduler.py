@@ -40,6 +40,7 @@ class SeededDeviceNoise:
 
 class NativeEulerScheduler:
     order = 1
+    kind = "euler"
 
     def __init__(self, ancestral: bool, timestep_spacing: Optional[str] = None, device="cuda"):
         self.ancestral = ancestral
@@ -110,5 +111,78 @@ class NativeEulerScheduler:
         noise = self.draw_noise(sample.shape, sample.device) if self.ancestral else None
         out = ops.euler_step(sample.contiguous(), model_output.contiguous(), params, noise=noise,
                              ancestral=self.ancestral)
+        self._step_index += 1
+        return (out,)
+
+    def device_step(self, latents, eps, params, noise=None, cfg=False):
+        """The batched step of the native loops (native/pipe.py): one launch for all samples, per-sample rows in ``params``."""
+        return ops.euler_step(latents, eps, params, noise=noise, cfg=cfg, ancestral=self.ancestral)
+
+
+class NativeDDIMScheduler:
+    """DDIM (eta = 0, epsilon prediction) as diffusers configures it for SD / SDXL: scaled-linear betas, leading spacing,
+    steps_offset = 1, set_alpha_to_one = False, clip_sample = False.  Host side = the fp32 abar table built exactly as
+    diffusers builds it (``torch.cumprod`` of fp32 alphas) and the per-step coefficients; the tensor work is
+    ``lb_ddim_step_f16``.  Same interface as :class:`NativeEulerScheduler` (``step_row`` / ``device_step`` for the native loops,
+    ``scale_model_input`` / ``step`` for the generic diffusers-style loop); ``scale_model_input`` is the identity and
+    ``init_noise_sigma`` is 1.  Reached from /root/reference/latentblending/diffusers_holder.py:330,356 when a pipe carries
+    this scheduler (``NativeSDXLPipe(scheduler="ddim")``); the reference's own SDXL pipes carry Euler schedulers (:42)."""
+    order = 1
+    kind = "ddim"
+    ancestral = False
+    init_noise_sigma = 1.0
+
+    def __init__(self, device="cuda"):
+        self.device = device
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, NUM_TRAIN_TIMESTEPS, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)            # fp32, as diffusers holds it
+        self.final_alpha_cumprod = self.alphas_cumprod[0]                   # set_alpha_to_one = False
+        self.noise_source = None
+        self._step_index = None
+        self.set_timesteps(30)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        n = int(num_inference_steps)
+        ratio = NUM_TRAIN_TIMESTEPS // n
+        ts = (np.arange(0, n) * ratio).round()[::-1].copy().astype(np.int64) + 1          # leading, steps_offset = 1
+        self.timesteps_np = ts.astype(np.float32)
+        self.timesteps = torch.from_numpy(self.timesteps_np)
+        self.num_inference_steps = n
+        self._ratio = ratio
+        self._step_index = None
+
+    def index_of(self, t) -> int:
+        return int(np.nonzero(self.timesteps_np == float(t))[0][0])
+
+    def alpha_pair(self, i: int):
+        """(abar_t, abar_prev) of step ``i`` as 0-dim fp32 tensors (prev_timestep = t - 1000 // n; below 0: final_alpha_cumprod)."""
+        t = int(self.timesteps_np[i])
+        prev = t - self._ratio
+        return self.alphas_cumprod[t], (self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod)
+
+    def step_row(self, i: int, guidance: float = 0.0):
+        """(0, sqrt(abar_t), sqrt(abar_prev), guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev)) in fp32 tensor arithmetic, the
+        scalars diffusers forms inside DDIMScheduler.step (beta_prod_t ** 0.5, alpha_prod_t ** 0.5, ...)."""
+        a_t, a_p = self.alpha_pair(i)
+        return (0.0, float(a_t ** 0.5), float(a_p ** 0.5), guidance, float((1 - a_t) ** 0.5), float((1 - a_p) ** 0.5))
+
+    def _locate(self, t) -> int:
+        if self._step_index is None:
+            self._step_index = self.index_of(float(t))
+        return self._step_index
+
+    def scale_model_input(self, sample: torch.Tensor, timestep=None) -> torch.Tensor:
+        return sample
+
+    def draw_noise(self, shape, device) -> torch.Tensor:        # (never used: eta = 0)
+        return torch.zeros(shape, device=device, dtype=torch.float16)
+
+    def device_step(self, latents, eps, params, noise=None, cfg=False):
+        return ops.ddim_step(latents, eps, params, cfg=cfg)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=False, **_):
+        i = self._locate(timestep)
+        params = ops.step_params([self.step_row(i)] * sample.shape[0], sample.device)
+        out = ops.ddim_step(sample.contiguous(), model_output.contiguous(), params)
         self._step_index += 1
         return (out,)

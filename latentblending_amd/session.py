@@ -10,8 +10,11 @@ Here the weights, launch programs and hipGraphs stay shared (one engine per mode
 READS OR LEAVES BEHIND that belongs to a user lives in an :class:`EngineSession`: prompts and their embeddings, negative
 prompt, seeds, size, step count, guidance, crossfeed settings, the branching plan, the transition tree (latents, frames,
 fractions, similarities) and an optional private noise source.  ``with session.bound() as be:`` takes the router's lock,
-installs the session's state on the shared engine, runs the user's calls, and stores what they left behind back into the
-session - calls of different users can interleave in any order and each sees an engine that nobody else touched.
+installs the session's state on the shared engine, runs the user's calls, stores what they left behind back into the
+session and RESTORES the engine - calls of different users can interleave in any order and each sees an engine that nobody
+else touched.  New users start from the defaults the router captured when it was built (round 5: a session used to copy
+the live engine at registration and bound() left the last user's state on it - a user registered after, or during,
+somebody's block inherited that user's prompts, embeddings and preset frames).
 
 Persistence is the reference's ``get_state_dict`` + ``yml_save`` (``blending_engine.py:709-728``, ``utils.py:245-262``);
 ``BlendingEngine.load_state_dict`` is the missing inverse, so ``get_state_dict -> yml_save -> yml_load -> load_state_dict``
@@ -39,29 +42,67 @@ _HOLDER_FIELDS = ("negative_prompt", "guidance_scale", "num_inference_steps", "w
                   "height_latent")
 
 
-class EngineSession:
-    """One user's view of a shared ``BlendingEngine``."""
+# of those, what a finished or prepared RUN leaves behind (never part of a new user's defaults)
+_TRANSIENT_FIELDS = ("image1_lowres", "image2_lowres", "multi_transition_img_first", "multi_transition_img_last",
+                     "_preset_anchor_frames")
 
-    def __init__(self, be, lock: Optional[threading.RLock] = None, noise_source=None):
+
+def _snapshot(be):
+    """(engine fields, holder fields, tree) of ``be`` as they are now; mutable containers are copied."""
+    return ({k: copy.copy(getattr(be, k)) for k in _ENGINE_FIELDS}, {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}, be._tree)
+
+
+def _install(be, engine, holder, tree):
+    for k, v in engine.items():
+        setattr(be, k, v)
+    for k, v in holder.items():
+        setattr(be.dh, k, v)
+    be._tree = tree
+    be.dh.set_num_inference_steps(holder["num_inference_steps"])           # scheduler tables are pipe state
+
+
+class EngineSession:
+    """One user's view of a shared ``BlendingEngine``.
+
+    A session starts from ``defaults`` - the (engine fields, holder fields) snapshot its router took of the engine when the
+    ROUTER was built - never from whatever the shared engine happens to hold when the user registers; run leftovers
+    (preset anchor frames, multi-transition images) are cleared and the tree is empty.  Without a router
+    (``EngineSession(be)``) the snapshot is taken here, under the session's lock.  ``bound()`` puts the engine back the way
+    it found it, so nothing a user did stays on the shared object between blocks."""
+
+    def __init__(self, be, lock: Optional[threading.RLock] = None, noise_source=None, defaults=None):
         self.be = be
         self._lock = lock if lock is not None else threading.RLock()
         self.noise_source = noise_source            # optional private ancestral-noise source (native pipes)
-        self._engine = {k: copy.copy(getattr(be, k)) for k in _ENGINE_FIELDS}
+        if defaults is None:
+            with self._lock:
+                if getattr(be, "_bound_session", None) is not None:
+                    raise RuntimeError("EngineSession: the engine is inside another session's bound() block; build sessions "
+                                       "from a SessionRouter (defaults taken once) or outside bound()")
+                defaults = _snapshot(be)[:2]
+        self._engine = {k: copy.copy(v) for k, v in defaults[0].items()}
+        for k in _TRANSIENT_FIELDS:
+            self._engine[k] = None
         self._engine["stats"] = {}
-        self._holder = {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}
+        self._holder = dict(defaults[1])
         self._tree = TransitionTree()               # a user never sees another user's tree
 
     @contextlib.contextmanager
     def bound(self):
-        """Install this session on the shared engine for the duration of the block (exclusive)."""
+        """Install this session on the shared engine for the duration of the block (exclusive), then put the engine back.
+        Re-entering the SAME session on the same thread is a no-op; binding a second session inside the block raises."""
         be = self.be
         with self._lock:
-            for k, v in self._engine.items():
-                setattr(be, k, v)
-            for k, v in self._holder.items():
-                setattr(be.dh, k, v)
-            be._tree = self._tree
-            be.dh.set_num_inference_steps(self._holder["num_inference_steps"])     # scheduler tables are pipe state
+            active = getattr(be, "_bound_session", None)
+            if active is self:                      # (re-entrant use of one session: already installed)
+                yield be
+                return
+            if active is not None:
+                raise RuntimeError("EngineSession.bound(): another session is bound to this engine on this thread - "
+                                   "sessions do not nest (leave the first block before entering the second)")
+            saved = _snapshot(be)
+            _install(be, self._engine, self._holder, self._tree)
+            be._bound_session = self
             sched = getattr(be.dh.pipe, "scheduler", None)
             swap_noise = self.noise_source is not None and hasattr(sched, "noise_source")
             if swap_noise:
@@ -74,6 +115,8 @@ class EngineSession:
                 self._engine = {k: getattr(be, k) for k in _ENGINE_FIELDS}
                 self._holder = {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}
                 self._tree = be._tree
+                be._bound_session = None
+                _install(be, *saved)                # the shared engine keeps nothing of this user
 
     # conveniences mirroring what the UI holder calls (gradio_ui.py:139-149, 238-256)
     def run_transition(self, **kw):
@@ -96,12 +139,17 @@ class SessionRouter:
     def __init__(self, engines: Dict[str, object]):
         self.dict_blendingengines = dict(engines)
         self._locks = {m: threading.RLock() for m in self.dict_blendingengines}
+        # every user's starting point: the engines as the OPERATOR configured them, captured once, here
+        self._defaults = {}
+        for m, be in self.dict_blendingengines.items():
+            with self._locks[m]:
+                self._defaults[m] = _snapshot(be)[:2]
         self.user_sessions: Dict[str, EngineSession] = {}
 
     def register_new_user(self, model: str, width: int, height: int, noise_source=None) -> str:
         user_id = str(uuid.uuid4().hex.upper()[0:8])
         be = self.dict_blendingengines[model]
-        session = EngineSession(be, self._locks[model], noise_source=noise_source)
+        session = EngineSession(be, self._locks[model], noise_source=noise_source, defaults=self._defaults[model])
         with session.bound() as engine:
             engine.set_dimensions((width, height))
         self.user_sessions[user_id] = session

@@ -15,7 +15,12 @@ Fixtures
   configs.json    BASELINE.json configs[2..4] at their STATED tree shape on the tiny CPU oracle pipe, run by the unchanged
                   reference: cfg 3 (base, 30 steps, depth 0.5, 15 branches, guidance 4.0 -> five injection levels), cfg 4
                   (turbo, 64 branches, one level), cfg 5 (base, 30 steps, 6 prompts chained with swap_forward +
-                  recycle_img1 as in example_multi_trans.py:39-58)
+                  recycle_img1 as in example_multi_trans.py:39-58); every frame also as a 16 x 16 box-downsample.
+                  cfg4_skew (round 5): cfg 4 again under a metric WITH SPREAD - the reference's tree logic untouched, its
+                  perceptual distance multiplied by |fb - fa|^5 x exp(4.4 x mean position of the two frames) (PositionSkewed
+                  below) - because under plain LPIPS the tiny synthetic model gives 64 gap distances within 0.5 % of each
+                  other and the 64th split is below the noise floor of any fp16 pipeline; here every greedy choice is clear of
+                  the runner-up by the margin stored in "min_separation" (asserted >= 5 %)
   frames.json     add_frames_linear_interp of the reference (utils.py:105-178) on seeded uint8 key frames with a seeded
                   numpy RNG: per-gap insert counts and a checksum of every output frame (numpy 2.x arithmetic: the
                   float32 frames are blended in float64)
@@ -27,6 +32,7 @@ from __future__ import annotations
 import hashlib
 import json
 import os
+import re
 
 import numpy as np
 import torch
@@ -184,6 +190,11 @@ def scheduler_fixture():
         "trailing4_ancestral": [[3.91930, 1.13999], [1.48163, 0.63733], [0.62591, 0.29793], [0.0, 0.0]],
         "leading30_first": 958, "leading30_last": 1, "leading30_sigma0": 11.47685, "leading30_init_noise_sigma": 11.52033,
         "source": "closed form from SDXL scaled_linear betas [0.00085, 0.012], 1000 steps (SURVEY.md §4)",
+        # DDIM (round 5): abar_t = prod_{s<=t} (1 - beta_s) in float64, leading spacing with steps_offset 1
+        "ddim_alphas_cumprod": {"0": 0.99915, "1": 0.9982960278384514, "34": 0.9678813931124362, "925": 0.0108601253829753,
+                                "958": 0.007534772714533716, "999": 0.004660098513077238},
+        "ddim_leading30_timesteps_head": [958, 925, 892, 859], "ddim_leading30_timesteps_tail": [67, 34, 1],
+        "ddim_final_alpha_cumprod": 0.99915,
     }
 
 
@@ -223,9 +234,71 @@ def tree_fixture(ref):
     return runs
 
 
+def box16(img):
+    """16 x 16 box-downsample of a frame's channel mean (0..255), rounded to 0.01 grey levels: 256 numbers per frame."""
+    a = np.asarray(img).astype(np.float64).mean(axis=2)
+    h, w = a.shape
+    return [round(float(v), 2) for v in a.reshape(16, h // 16, 16, w // 16).mean(axis=(1, 3)).flatten()]
+
+
+def spread_weight(fa, fb, skew, width_power):
+    """The factor the spread metric multiplies a perceptual distance by: |fb - fa|^width_power x exp(skew x mean position).
+    None (an anchor compared before the tree exists) counts as its end of the axis."""
+    import math
+    fa, fb = (0.0 if fa is None else float(fa)), (1.0 if fb is None else float(fb))
+    return abs(fb - fa) ** width_power * math.exp(skew * 0.5 * (fa + fb))
+
+
+def position_skewed_engine(ref, skew, width_power):
+    """The reference's BlendingEngine with ONE quantity changed: the perceptual distance of two frames is multiplied by
+    spread_weight(their positions on the transition axis).  get_mixing_parameters / compute_latents_mix / insert_into_tree /
+    run_transition are the reference's own code; the subclass only remembers the fraction of the frame being inserted
+    (insert_into_tree's argument) so that the wrapped distance can look positions up, and records how far the greedy argmax
+    was clear of the runner-up at every choice.
+
+    Why this shape.  On the tiny synthetic model plain LPIPS gives gaps of one width distances within 0.5 % of each other and
+    a factor ~2.9 between widths.  exp(skew x position) alone separates neighbours of one width by exp(skew x width) but lets
+    a narrow gap far right tie with a wide gap far left (measured: some choice within 0.3 % for every skew in 1.5..6); the
+    width power makes a halving worth more than the whole position range (2.9 x 2^5 = 92 > e^4.4 = 81), so the greedy
+    order is level by level, right to left, and every choice is >= 5 % clear."""
+
+    class PositionSkewed(ref.BlendingEngine):
+        _fract_new = None
+        separations = None
+
+        def _position(self, img):
+            for f, im in zip(self.tree_fracts, self.tree_final_imgs):
+                if im is img:
+                    return float(f)
+            return self._fract_new
+
+        def get_lpips_similarity(self, imgA, imgB):
+            d = super().get_lpips_similarity(imgA, imgB)
+            return d * spread_weight(self._position(imgA), self._position(imgB), skew, width_power)
+
+        def insert_into_tree(self, fract_mixing, idx_injection, list_latents):
+            self._fract_new = fract_mixing
+            try:
+                return super().insert_into_tree(fract_mixing, idx_injection, list_latents)
+            finally:
+                self._fract_new = None
+
+        def get_mixing_parameters(self, idx_injection):
+            if self.separations is None:
+                self.separations = []
+            sims = [s for s in self.tree_similarities if isinstance(s, float)]
+            if len(sims) >= 2:
+                top = sorted(sims)[-2:]
+                self.separations.append(top[1] / top[0])
+            return super().get_mixing_parameters(idx_injection)
+
+    return PositionSkewed
+
+
 def snapshot(be, imgs, p):
     """What the tests compare of one finished run_transition."""
     return {
+        "frame_ds16": [box16(i) for i in imgs],
         "frames": len(imgs), "unet_calls": p.unet.calls, "vae_calls": p.vae.calls, "noise_draws": p.noise.draws,
         "list_idx_injection": [int(i) for i in be.list_idx_injection], "list_nmb_stems": [int(s) for s in be.list_nmb_stems],
         "tree_fracts": [float(f) for f in be.tree_fracts], "tree_idx_injection": [int(i) for i in be.tree_idx_injection],
@@ -242,6 +315,7 @@ CFG5_PROMPTS = ["lake and forest", "alien desolate landscapes", "psychedelic sky
                 "fog over a harbour", "desert under two moons"]
 CFG5_SEEDS = [420, 421, 977, 12, 90001, 5]
 CFG5_NEGATIVE = "blurry, pale, low-res, lofi"
+CFG4_SKEW, CFG4_WIDTH_POWER = 4.4, 5.0
 
 
 def configs_fixture(ref):
@@ -275,6 +349,23 @@ def configs_fixture(ref):
         p.unet.calls = p.vae.calls = 0
         imgs = be.run_transition(fixed_seeds=[420, 421])
     out["cfg4"] = snapshot(be, imgs, p)
+    # cfg 4 under a metric with spread (see position_skewed_engine)
+    p = tiny_pipe(turbo=True)
+    np.random.seed(0)
+    with H.cuda_is_identity():
+        be = position_skewed_engine(ref, CFG4_SKEW, CFG4_WIDTH_POWER)(p)
+        be.set_dimensions((128, 128))
+        be.set_branching(nmb_max_branches=64)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        p.noise.reset()
+        p.unet.calls = p.vae.calls = 0
+        imgs = be.run_transition(fixed_seeds=[420, 421])
+    out["cfg4_skew"] = snapshot(be, imgs, p)
+    out["cfg4_skew"].update(metric="reference LPIPS x |fb - fa|^width_power x exp(skew x mean position of the two frames)",
+                            skew=CFG4_SKEW, width_power=CFG4_WIDTH_POWER,
+                            min_separation=float(min(be.separations)), last_separation=float(be.separations[-1]))
+    assert min(be.separations) >= 1.05, ("cfg4_skew: a greedy choice within 5 % of the runner-up", min(be.separations))
     # cfg 5: example_multi_trans.py:39-58 with 6 prompts on the base model
     p = tiny_pipe(turbo=False)
     np.random.seed(0)
@@ -331,8 +422,11 @@ def main():
     for name, make in makers:
         if only and name not in only:
             continue
+        text = json.dumps(make(), indent=1)
+        # (rows of plain numbers on one line each: the 16 x 16 downsamples would otherwise be 40 k lines)
+        text = re.sub(r"\[\s*((?:-?[0-9.e+-]+,\s*)+-?[0-9.e+-]+)\s*\]", lambda m: "[" + re.sub(r"\s+", " ", m.group(1)) + "]", text)
         with open(os.path.join(OUT, name + ".json"), "w") as fh:
-            json.dump(make(), fh, indent=1)
+            fh.write(text)
         print("wrote", name)
 
 

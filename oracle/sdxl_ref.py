@@ -342,6 +342,38 @@ def make_timesteps(n: int, spacing: str) -> np.ndarray:
     raise ValueError(spacing)
 
 
+class DDIMScheduler:
+    """diffusers DDIMScheduler as SD / SDXL configure it (scaled-linear betas, leading spacing, steps_offset 1,
+    set_alpha_to_one False, clip_sample False), eta = 0, epsilon prediction - restated from its published algorithm
+    (diffusers 0.25.0 schedulers/scheduling_ddim.py: set_timesteps, step formulas (12) / (16) of the DDIM paper).  Like
+    diffusers it does NOT upcast: the tensor arithmetic runs in the sample's dtype with 0-dim fp32 coefficients."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self):
+        betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self.set_timesteps(30)
+
+    def set_timesteps(self, n, device=None):
+        self.num_inference_steps = n
+        self.timesteps = torch.from_numpy((np.arange(0, n) * (1000 // n)).round()[::-1].copy().astype(np.int64) + 1)
+
+    def scale_model_input(self, sample, t=None):
+        return sample
+
+    def step(self, model_output, t, sample, eta=0.0, generator=None, return_dict=False, **_):
+        t = int(t)
+        prev_t = t - 1000 // self.num_inference_steps
+        alpha_prod_t = self.alphas_cumprod[t]
+        alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        beta_prod_t = 1 - alpha_prod_t
+        pred_original_sample = (sample - beta_prod_t ** (0.5) * model_output) / alpha_prod_t ** (0.5)
+        pred_sample_direction = (1 - alpha_prod_t_prev) ** (0.5) * model_output
+        return (alpha_prod_t_prev ** (0.5) * pred_original_sample + pred_sample_direction,)
+
+
 class EulerScheduler:
     """Euler (``ancestral=False``, SDXL base: leading spacing, offset 1) and Euler-ancestral
     (``ancestral=True``, SDXL-Turbo: trailing spacing), epsilon prediction."""

@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 from oracle import pipe as OP  # noqa: E402  (checker only: the noise tape and the tiny configs)
 from oracle import sdxl_ref as R  # noqa: E402
 
-from _baseline_cfgs import (check_cfg4_sequential, check_structure, check_structure_cfg4_batched, check_values, gold_configs, setup_cfg3,  # noqa: E402
-                            setup_cfg4, setup_cfg5)
+from _baseline_cfgs import (box16, check_structure, check_structure_cfg4_plain, check_values, gold_configs, lpips_base, setup_cfg3,  # noqa: E402
+                            setup_cfg4, setup_cfg5, spread_metric)
 
-GPU_TOL = dict(sim_rtol=5e-2, norm_rtol=3e-2, mean_tol=1.0, head_tol=4)
+GPU_TOL = dict(sim_rtol=5e-2, norm_rtol=3e-2, mean_tol=1.0, head_tol=4, ds_tol=2.0)
 
 
 def native_pipe(turbo):
@@ -49,9 +49,74 @@ def test_cfg3_stated_tree_native(frontier, results_log):
                                                            "sims": [float(s) for s in be.tree_similarities]}
 
 
+def native_spread_metric(pipe, c):
+    return spread_metric(c, lambda a, b: pipe.native_frame_distances([(a, b)])[0])
+
+
+def test_cfg4_stated_tree_native_sequential(results_log):
+    """SDXL-Turbo, 4 steps, 64 branches on one level (66 frames), sequential engine, under the metric with spread (fixture
+    cfg4_skew: the reference's tree logic, every greedy choice >= 5 % clear): IDENTICAL tree, commit order and noise draws,
+    similarities / latents / every frame (16 x 16 downsample of all 66) within the fp16 tolerance."""
+    from latentblending_amd import BlendingEngine
+    c = gold_configs()["cfg4_skew"]
+    p, tape = native_pipe(True)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=1)
+    be.pair_metric = native_spread_metric(p, c)
+    setup_cfg4(be)
+    tape.reset()
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    check_structure(be, imgs, c)
+    check_values(be, imgs, c, **GPU_TOL)
+    results_log["cfg4_spread_metric_sequential"] = {"frames": len(imgs), "same_tree": True, "min_separation_of_fixture": c["min_separation"]}
+
+
+def test_cfg4_stated_tree_native_frontier64_matches_oracle_engine(results_log):
+    """The same config as ONE speculative frontier of 64 (fused wavefront + virtual gaps: the form an 8-GPU farm runs) against
+    the ORACLE engine - this repo's host layer on the CPU fp32 oracle pipe - run at the SAME frontier width with the same
+    noise tape (a batched frontier consumes the ancestral tape in evaluation order, so the sequential reference run is not the
+    comparison): identical tree = the reference's (fixture), then every frame, final latent and similarity numerically."""
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    c = gold_configs()["cfg4_skew"]
+    p, tape = native_pipe(True)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=64)
+    be.pair_metric = native_spread_metric(p, c)
+    setup_cfg4(be)
+    tape.reset()
+    imgs = be.run_transition(fixed_seeds=[420, 421])
+    check_structure(be, imgs, c)                                  # the reference's tree
+    op = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+    lp = R.OracleLPIPS(7)
+    set_backend(R.TorchCpuBackend())
+    try:
+        np.random.seed(0)
+        ob = BlendingEngine(op, metric=lp, verbose=False, frontier_width=64)
+        ob.pair_metric = spread_metric(c, lpips_base(lp))
+        setup_cfg4(ob)
+        op.noise.reset()
+        want = ob.run_transition(fixed_seeds=[420, 421])
+    finally:
+        set_backend(None)
+    assert [float(f) for f in ob.tree_fracts] == [float(f) for f in be.tree_fracts] == c["tree_fracts"]
+    assert be.stats.get("frontier_rounds", 0) == ob.stats.get("frontier_rounds", 0)
+    sims, osims = np.array([float(x) for x in be.tree_similarities]), np.array([float(x) for x in ob.tree_similarities])
+    assert np.allclose(sims, osims, rtol=GPU_TOL["sim_rtol"]), (sims.tolist(), osims.tolist())
+    worst_ds = worst_mean = 0.0
+    for k, (a, b, la, lb) in enumerate(zip(imgs, want, be.tree_latents, ob.tree_latents)):
+        worst_ds = max(worst_ds, float(np.abs(box16(a) - box16(b)).max()))
+        worst_mean = max(worst_mean, abs(float(np.asarray(a).mean()) - float(np.asarray(b).mean())))
+        n = float(lb[-1].float().norm())
+        assert abs(float(la[-1].float().norm()) - n) <= GPU_TOL["norm_rtol"] * n, k
+    assert worst_ds <= GPU_TOL["ds_tol"] and worst_mean <= GPU_TOL["mean_tol"], (worst_ds, worst_mean)
+    results_log["cfg4_spread_metric_frontier64"] = {"frames": len(imgs), "same_tree_as_reference": True, "rounds": be.stats.get("frontier_rounds", 0),
+                                                    "worst_ds16_cell": worst_ds, "worst_frame_mean": worst_mean}
+
+
 @pytest.mark.parametrize("frontier", [1, 64])
-def test_cfg4_stated_tree_native(frontier, results_log):
-    """SDXL-Turbo, 4 steps, 64 branches on one level (66 frames); frontier 64 = the fused wavefront + virtual gaps."""
+def test_cfg4_plain_lpips_structure_native(frontier, results_log):
+    """cfg 4 under plain LPIPS (fixture cfg4): the structural facts - grid filled, census, injection indices."""
     from latentblending_amd import BlendingEngine
     c = gold_configs()["cfg4"]
     p, tape = native_pipe(True)
@@ -60,14 +125,8 @@ def test_cfg4_stated_tree_native(frontier, results_log):
     setup_cfg4(be)
     tape.reset()
     imgs = be.run_transition(fixed_seeds=[420, 421])
-    assert len(imgs) == 66
-    same = True
-    if frontier == 1:       # (identical tree, or the 64th split on a near tie of the reference's choice: see check_cfg4_sequential)
-        same = check_cfg4_sequential(be, imgs, c, GPU_TOL)
-    else:                   # (a batched frontier consumes the ancestral noise tape in evaluation order, not in commit order)
-        check_structure_cfg4_batched(be, imgs, c)
-    results_log[f"cfg4_stated_tree_frontier{frontier}"] = {"frames": len(imgs), "same_tree": same,
-                                                           "rounds": be.stats.get("frontier_rounds", 0)}
+    check_structure_cfg4_plain(be, imgs, c)
+    results_log[f"cfg4_plain_lpips_frontier{frontier}"] = {"frames": len(imgs), "rounds": be.stats.get("frontier_rounds", 0)}
 
 
 @pytest.mark.parametrize("frontier", [1, 16])

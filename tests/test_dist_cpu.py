@@ -94,7 +94,7 @@ def _cfg4_worker(rank, world, port, out_dir):
     from latentblending_amd import BlendingEngine
     from latentblending_amd.backend import set_backend
     from latentblending_amd.dist import BranchFarm
-    from _baseline_cfgs import check_structure_cfg4_batched, gold_configs, setup_cfg4
+    from _baseline_cfgs import check_structure_cfg4_plain, gold_configs, setup_cfg4
     set_backend(R.TorchCpuBackend())
     c = gold_configs()["cfg4"]
     p = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
@@ -105,7 +105,7 @@ def _cfg4_worker(rank, world, port, out_dir):
     p.noise.reset()
     p.unet.calls = p.vae.calls = 0
     imgs = be.run_transition(fixed_seeds=[420, 421])
-    check_structure_cfg4_batched(be, imgs, c)
+    check_structure_cfg4_plain(be, imgs, c)
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)).tobytes()).hexdigest()[:16]
     res = {"sims": [float(s) for s in be.tree_similarities], "latent_sha": [sha(l[-1]) for l in be.tree_latents],
            "frame_sha": [sha(i) for i in imgs], "unet_calls": p.unet.calls, "vae_calls": p.vae.calls,

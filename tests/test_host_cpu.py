@@ -111,6 +111,37 @@ def test_scheduler_tables_match_closed_form():
         assert abs(s.init_noise_sigma - g["leading30_init_noise_sigma"]) < 2e-4
 
 
+def test_ddim_tables_and_step_match_closed_form():
+    """DDIM (north_star: "the Euler/DDIM step"): the abar table and leading-spaced timesteps of the oracle restatement against
+    float64 closed-form known answers (tests/golden/scheduler.json), the native host scheduler equal to the oracle's, and the
+    oracle's step against the DDIM paper's formula evaluated in float64."""
+    from latentblending_amd.native.scheduler import NativeDDIMScheduler
+    g = gold("scheduler")
+    o, n = R.DDIMScheduler(), NativeDDIMScheduler(device="cpu")
+    for t, want in g["ddim_alphas_cumprod"].items():
+        assert abs(float(o.alphas_cumprod[int(t)]) - want) <= 2e-6 * want          # (fp32 cumprod of 1000 factors)
+    assert abs(float(o.final_alpha_cumprod) - g["ddim_final_alpha_cumprod"]) < 1e-7
+    for k in (30, 6, 50, 4):
+        o.set_timesteps(k); n.set_timesteps(k)
+        assert o.timesteps.tolist() == [int(t) for t in n.timesteps.tolist()]
+    o.set_timesteps(30); n.set_timesteps(30)
+    assert o.timesteps[:4].tolist() == g["ddim_leading30_timesteps_head"] and o.timesteps[-3:].tolist() == g["ddim_leading30_timesteps_tail"]
+    assert torch.equal(o.alphas_cumprod, n.alphas_cumprod) and n.init_noise_sigma == 1.0
+    x, e = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(5)), torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(6))
+    assert n.scale_model_input(x, 958) is x
+    for i in (0, 7, 29):                                    # (29: prev_timestep < 0 -> final_alpha_cumprod)
+        t = int(o.timesteps[i])
+        a_t, a_p = n.alpha_pair(i)
+        prev = t - 1000 // 30
+        assert float(a_t) == float(o.alphas_cumprod[t]) and float(a_p) == float(o.alphas_cumprod[prev] if prev >= 0 else o.final_alpha_cumprod)
+        row = n.step_row(i, 2.5)
+        at, ap = float(a_t), float(a_p)
+        assert row[0] == 0.0 and row[3] == 2.5 and np.allclose(row[1:3] + row[4:6], [at ** 0.5, ap ** 0.5, (1 - at) ** 0.5, (1 - ap) ** 0.5], rtol=1e-6)
+        got = o.step(e, t, x)[0].double()
+        want = ap ** 0.5 * (x.double() - (1 - at) ** 0.5 * e.double()) / at ** 0.5 + (1 - ap) ** 0.5 * e.double()
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
 def test_native_scheduler_tables_equal_oracle():
     from latentblending_amd.native.scheduler import NativeEulerScheduler
     for anc, n in [(True, 4), (True, 2), (False, 30), (False, 6), (False, 50)]:

@@ -208,6 +208,43 @@ def test_euler_step_matches_oracle(ancestral, results_log):
     assert worst <= 1
 
 
+@pytest.mark.parametrize("cfg", [False, True])
+def test_ddim_step_matches_oracle(cfg, results_log):
+    """lb_ddim_step_f16 (eta = 0) against the oracle restatement of diffusers' DDIMScheduler.step on fp16 tensors - which, like
+    diffusers, rounds every tensor operation to fp16 - at the first, a middle and the last step (prev_timestep < 0), with and
+    without the fp16 CFG combine of diffusers_holder.py:347-349: <= 1 fp16 ulp (the kernel rounds in the same six places)."""
+    from latentblending_amd.native.scheduler import NativeDDIMScheduler
+    o = ops()
+    sched, ref = NativeDDIMScheduler(device=DEV), R.DDIMScheduler()
+    sched.set_timesteps(30); ref.set_timesteps(30)
+    B, g = 3, 4.0
+    x = rnd(B, 4, 64, 64, seed=401, scale=3.0)
+    eps = rnd(2 * B if cfg else B, 4, 64, 64, seed=402)
+    worst = 0
+    for i in (0, 13, 29):
+        t = int(ref.timesteps[i])
+        e = eps
+        if cfg:             # noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond), fp16 tensor arithmetic
+            eu, et = eps[:B], eps[B:]
+            e = eu + g * (et - eu)
+        want = ref.step(e, t, x)[0]
+        assert want.dtype == torch.float16
+        params = o.step_params([sched.step_row(i, g)] * B, DEV)
+        got = o.ddim_step(x.to(DEV), eps.to(DEV), params, cfg=cfg)
+        worst = max(worst, ulp_diff_f16(got, want))
+        # and through the diffusers-style API of the native scheduler (no CFG there: the caller combines)
+        if not cfg:
+            sched._step_index = None
+            assert torch.equal(sched.step(eps.to(DEV), float(t), x.to(DEV))[0], got)
+    results_log[f"ddim_step_cfg{int(cfg)}_max_ulp"] = worst
+    print(f"[parity] ddim step cfg={cfg}: max ulp {worst}")
+    assert worst <= 1
+    # odd sizes (no 16-byte vectors)
+    xs, es = rnd(2, 4, 5, 7, seed=403), rnd(2, 4, 5, 7, seed=404)
+    params = o.step_params([sched.step_row(5)] * 2, DEV)
+    assert ulp_diff_f16(o.ddim_step(xs.to(DEV), es.to(DEV), params), ref.step(es, int(ref.timesteps[5]), xs)[0]) <= 1
+
+
 def test_euler_cfg_combine(results_log):
     o = ops()
     x = rnd(1, 4, 32, 32, seed=18, scale=4.0)

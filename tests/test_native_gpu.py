@@ -192,6 +192,45 @@ def test_transition_tree_matches_oracle(turbo, results_log):
     assert same_tree, (be_o.tree_fracts, be_p.tree_fracts)
 
 
+@pytest.mark.parametrize("frontier", [1, 8])
+def test_transition_with_ddim_scheduler_matches_oracle(frontier, results_log):
+    """The whole branched transition with DDIM (eta 0) on both sides - NativeSDXLPipe(scheduler="ddim") through the native
+    batched loops (lb_ddim_step_f16; the scale launch is the identity) against the engine on the CPU oracle pipe carrying the
+    oracle's DDIMScheduler under the generic step-by-step loop: base model, 6 steps, guidance 3.0 (CFG), two injection levels."""
+    import dataclasses as dc
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    n = native()
+    ucfg, vcfg = R.tiny_unet_cfg(), R.tiny_vae_cfg()
+    o = OP.StableDiffusionXLPipeline(turbo=False, unet_cfg=ucfg, vae_cfg=vcfg, seed=0)
+    o.scheduler = R.DDIMScheduler()
+    p = n.NativeSDXLPipe(turbo=False, unet_cfg=n.UNetConfig(**dc.asdict(ucfg)), vae_cfg=n.VAEConfig(**dc.asdict(vcfg)), seed=0, scheduler="ddim")
+    assert p.scheduler.kind == "ddim" and p.scheduler.init_noise_sigma == 1.0
+    np.random.seed(0)
+    set_backend(R.TorchCpuBackend())
+    be_o = BlendingEngine(o, metric=R.OracleLPIPS(7), verbose=False)
+    set_backend(None)
+    be_p = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=frontier)
+    for be in (be_o, be_p):
+        be.set_dimensions((128, 128))
+        be.set_num_inference_steps(6)
+        be.set_guidance_scale(3.0)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=6)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+    set_backend(R.TorchCpuBackend())
+    imgs_o = be_o.run_transition(fixed_seeds=[420, 421])
+    set_backend(None)
+    imgs_p = be_p.run_transition(fixed_seeds=[420, 421])
+    assert len(imgs_o) == len(imgs_p) and be_o.tree_fracts == be_p.tree_fracts and be_o.tree_idx_injection == be_p.tree_idx_injection
+    lat_err = max(rel_l2(a[-1], b[-1]) for a, b in zip(be_p.tree_latents, be_o.tree_latents))
+    d = np.stack([np.abs(np.asarray(a).astype(np.int32) - np.asarray(b).astype(np.int32)) for a, b in zip(imgs_p, imgs_o)])
+    results_log[f"transition_ddim_frontier{frontier}"] = {"frames": len(imgs_p), "final_latent_rel_l2": lat_err, "mean_abs_u8": float(d.mean()),
+                                                          "frac_within_4": float((d <= 4).mean()), "same_tree": True}
+    print(f"[parity] DDIM transition frontier {frontier}: frames={len(imgs_p)} latent rel_l2={lat_err:.3e} mean|du8|={d.mean():.3f}")
+    assert lat_err <= 3e-2 and d.mean() <= 2 and (d <= 4).mean() >= 0.99
+
+
 def test_chained_transitions_match_oracle(results_log):
     """The multi-transition flow of the reference's example_multi_trans.py:39-58 - run_transition, swap_forward,
     new prompt2, run_transition(recycle_img1=True) - native engine (HIP) vs the same engine on the CPU oracle pipe:

@@ -156,3 +156,70 @@ def test_sessions_serialise_concurrent_callers(cpu_backend):
         frames, steps = out[uid]
         with router.session(uid).bound() as be:
             assert be.num_inference_steps == steps and len(be.tree_latents[0]) == steps and len(frames) == len(be.tree_fracts)
+
+
+def test_new_users_never_inherit_another_users_state(cpu_backend):
+    """A user registered AFTER, or DURING, somebody else's bound() block starts from the router's defaults - not from the
+    prompts / embeddings / preset frames the shared engine happens to hold (round-4 advisor finding); bound() puts the
+    engine back; two different sessions do not nest."""
+    from latentblending_amd import BlendingEngine, EngineSession, SessionRouter
+    np.random.seed(0)
+    shared = BlendingEngine(tiny_pipe(True), metric=R.OracleLPIPS(7), verbose=False)
+    router = SessionRouter({"turbo": shared})
+    pristine = shared.text_embedding1           # (whatever a fresh engine holds: the operator's defaults)
+
+    def same_embedding(a, b):
+        import torch
+        if a is None or b is None:
+            return a is b
+        return len(a) == len(b) and all((x is None and y is None) or (x is not None and y is not None and torch.equal(x, y)) for x, y in zip(a, b))
+    ua = router.register_new_user("turbo", 64, 64)
+    with router.session(ua).bound() as be:
+        be.set_negative_prompt("secret negative")
+        be.set_prompt1("user A's private prompt"); be.set_prompt2("another private prompt")
+        be.set_branching(depth_strength=0.5, nmb_max_branches=3)
+        be._preset_anchor_frames = ["A's frame", None]
+        during = {}
+
+        def register_from_another_thread():     # (blocks on the engine lock until A's block ends)
+            during["uid"] = router.register_new_user("turbo", 64, 64)
+        t = threading.Thread(target=register_from_another_thread)
+        t.start()
+        with pytest.raises(RuntimeError):       # a second session inside A's block, same thread
+            with router.session(ua).__class__(shared, router._locks["turbo"], defaults=router._defaults["turbo"]).bound():
+                pass
+        with pytest.raises(RuntimeError):       # a router-less session built while the engine is bound
+            EngineSession(shared, router._locks["turbo"])
+    t.join()
+    # the shared engine holds nothing of user A
+    assert shared.prompt1 == "" and same_embedding(shared.text_embedding1, pristine) and shared.negative_prompt is None and shared._preset_anchor_frames is None
+    ub = router.register_new_user("turbo", 64, 64)
+    for uid in (ub, during["uid"]):
+        with router.session(uid).bound() as be:
+            assert be.prompt1 == "" and be.prompt2 == "" and same_embedding(be.text_embedding1, pristine) and same_embedding(be.text_embedding2, shared.text_embedding2)
+            assert be.negative_prompt is None and be._preset_anchor_frames is None and not be.tree_fracts
+    with router.session(ua).bound() as be:      # and A still has its own
+        assert be.prompt1 == "user A's private prompt" and be.negative_prompt == "secret negative" and be._preset_anchor_frames == ["A's frame", None]
+        with router.session(ua).bound() as again:       # the SAME session may re-enter
+            assert again is be
+
+
+def test_load_state_dict_resets_a_stale_negative_prompt(cpu_backend):
+    """A state saved WITHOUT a negative prompt, loaded into an engine that has one: the stale prompt must go (round-4 advisor
+    finding) - same frames as loading into a fresh engine."""
+    from latentblending_amd import BlendingEngine
+    np.random.seed(0)
+    src = BlendingEngine(tiny_pipe(False), metric=R.OracleLPIPS(7), verbose=False)
+    src.set_dimensions((64, 64)); src.set_num_inference_steps(4); src.set_guidance_scale(3.0)
+    src.set_branching(depth_strength=0.5, nmb_max_branches=3)
+    src.set_prompt1("a reef"); src.set_prompt2("an alien planet")
+    src.seed1, src.seed2 = 3, 4
+    state = src.get_state_dict()
+    assert state["negative_prompt"] is None
+    want = frames_of(src.run_transition())
+    dirty = BlendingEngine(tiny_pipe(False), metric=R.OracleLPIPS(7), verbose=False)
+    dirty.set_negative_prompt("blurry, pale, something stale")
+    dirty.load_state_dict(state)
+    assert dirty.negative_prompt is None and dirty.dh.negative_prompt == ""
+    got = frames_of(dirty.run_transition())
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
