@@ -2,7 +2,7 @@
 the bench process (phases_per_transition) and after a VAE was built (tools/epilogue_ab.py, round 5)?  One process: time the step
 graph (a) alone, (b) after the VAE decoder + its B=17 program exist and ran, (c) after also the B=2 program exists, (d) after the
 VAE objects were dropped and the allocator cache emptied, (e) with the step replayed back to back with the VAE decode (the
-bench's order).  Usage: LB_SYNTH_CACHE=/tmp python tools/residency_ab.py"""
+bench's order); (b') / (b'') separate a clock effect from a memory-placement effect.  Usage: LB_SYNTH_CACHE=/tmp python tools/residency_ab.py"""
 import os
 import sys
 
@@ -58,6 +58,10 @@ def main():
     print(f"    VAE decode B=17                              : {timed(vp.prog.launch):7.3f} ms", flush=True)
     for rep in range(2):
         print(f"(b) UNet B=17 step, VAE resident                 : {timed(p17.prog_step.launch):7.3f} ms   [{mem()}]", flush=True)
+    import time
+    time.sleep(5.0)         # (clocks / temperature: the VAE's halo convs run the chip at its power limit just before (b))
+    print(f"(b') the same after 5 s of idle                  : {timed(p17.prog_step.launch):7.3f} ms", flush=True)
+    print(f"(b'') and again immediately (20 iterations)      : {timed(p17.prog_step.launch, 20):7.3f} ms", flush=True)
     p2 = unet_prog(2)
     print(f"    UNet B=2 step                                : {timed(p2.prog_step.launch, 10):7.3f} ms", flush=True)
     print(f"(c) UNet B=17 step, VAE + B=2 program resident   : {timed(p17.prog_step.launch):7.3f} ms   [{mem()}]", flush=True)
