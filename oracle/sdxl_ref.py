@@ -369,9 +369,20 @@ class DDIMScheduler:
         alpha_prod_t = self.alphas_cumprod[t]
         alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         beta_prod_t = 1 - alpha_prod_t
-        pred_original_sample = (sample - beta_prod_t ** (0.5) * model_output) / alpha_prod_t ** (0.5)
-        pred_sample_direction = (1 - alpha_prod_t_prev) ** (0.5) * model_output
-        return (alpha_prod_t_prev ** (0.5) * pred_original_sample + pred_sample_direction,)
+        if sample.dtype != torch.float16:
+            pred_original_sample = (sample - beta_prod_t ** (0.5) * model_output) / alpha_prod_t ** (0.5)
+            pred_sample_direction = (1 - alpha_prod_t_prev) ** (0.5) * model_output
+            return (alpha_prod_t_prev ** (0.5) * pred_original_sample + pred_sample_direction,)
+        # fp16 tensors: the same expressions as torch evaluates them ON THE DEVICE - the 0-dim fp32 coefficients live on the
+        # host, so every kernel takes them as fp32 scalars (opmath), computes in fp32 and rounds its result to fp16.  (torch's
+        # CPU kernels would first round the coefficient itself to fp16: not what a GPU pipeline computes, so not restated.)
+        rt = lambda v: v.to(torch.float16).float()                                         # noqa: E731
+        sb_t, sa_t = float(beta_prod_t ** 0.5), float(alpha_prod_t ** 0.5)
+        sb_p, sa_p = float((1 - alpha_prod_t_prev) ** 0.5), float(alpha_prod_t_prev ** 0.5)
+        x, e = sample.float(), model_output.float()
+        x0 = rt(rt(x - rt(sb_t * e)) / sa_t)
+        direction = rt(sb_p * e)
+        return ((rt(sa_p * x0) + direction).to(torch.float16),)
 
 
 class EulerScheduler:

@@ -68,7 +68,7 @@ static void fill_half(std::vector<__half>& v, float scale) {
     for (auto& x : v) x = __float2half(frand() * scale);
 }
 
-struct Variant { const char* name; int tile; int splitk; int group; int lean = 1; };    // lean: lb_gemm_set_lean_epilogue
+struct Variant { const char* name; int tile; int splitk; int group; int lean = 1; int noepi = 0; };    // lean: lb_gemm_set_lean_epilogue; noepi: the launch WITHOUT bias / residual (what the rocBLAS row computes: alpha A W^T, beta = 0)
 
 int main(int argc, char** argv) {
     const std::string set = argc > 1 ? argv[1] : "b17";
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     if (set == "b17" || set == "all") shapes.insert(shapes.end(), std::begin(B17), std::end(B17));
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
-    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t1", 1, 1, 8}};
+    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t1", 1, 1, 8}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
     {
@@ -132,22 +132,22 @@ int main(int argc, char** argv) {
             if (i == 0) CK(hipMemcpy(dW[0], hW.data(), wbytes, hipMemcpyHostToDevice));
             else CK(hipMemcpy(dW[i], dW[0], wbytes, hipMemcpyDeviceToDevice));
         }
-        auto params = [&](int wi, __half* out) {
+        auto params = [&](int wi, __half* out, bool noepi = false) {
             LbGemmParams p;
             memset(&p, 0, sizeof(p));
             p.A = (const lb_half*)dA; p.W = (const lb_half*)dW[wi]; p.C = out;
             p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldw = s.K; p.ldc = n_out; p.ldr = n_out;
             p.rows_per_batch = s.M; p.alpha = 1.f; p.zero_page = zero_page; p.partial = dWs;
             if (s.geglu) p.flags |= LB_GEMM_GEGLU;
-            if (s.epi >= 1) p.bias = dB;
-            if (s.epi >= 2 && !s.geglu) p.residual = dR;
+            if (s.epi >= 1 && !noepi) p.bias = dB;
+            if (s.epi >= 2 && !s.geglu && !noepi) p.residual = dR;
             return p;
         };
         auto run = [&](const Variant& v, int wi, __half* out) {
             lb_gemm_set_tuning(v.tile, v.splitk);
             lb_gemm_pp_set_group(v.group);
             lb_gemm_set_lean_epilogue(v.lean);
-            LbGemmParams p = params(wi, out);
+            LbGemmParams p = params(wi, out, v.noepi != 0);
             const int rc = lb_gemm_f16(&p, stream);
             if (rc) { fprintf(stderr, "lb_gemm_f16 failed: %s\n", lb_last_error_string()); exit(3); }
         };
@@ -161,6 +161,7 @@ int main(int argc, char** argv) {
         double ref_abs = 0;
         for (auto& x : hCref) ref_abs = std::max(ref_abs, (double)std::fabs(__half2float(x)));
         for (int v = 1; v < NV; ++v) {
+            if (variants[v].noepi) continue;                           // (a different function: timing row only)
             CK(hipMemsetAsync(dC, 0xff, hC.size() * 2, stream));
             run(variants[v], 0, dC);
             CK(hipStreamSynchronize(stream));
