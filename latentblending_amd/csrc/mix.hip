@@ -570,12 +570,19 @@ __device__ __forceinline__ f16 ddim_one(f16 xh, f16 eu, f16 et, float sa_t, floa
         const f16 sc = (f16)(g * (float)diff);
         e = (f16)((float)eu + (float)sc);
     }
-    const f16 t1 = (f16)__fmul_rn(sb_t, (float)e);
-    const f16 t2 = (f16)__fsub_rn((float)xh, (float)t1);
-    const f16 x0 = (f16)__fdiv_rn((float)t2, sa_t);
-    const f16 dir = (f16)__fmul_rn(sb_p, (float)e);
-    const f16 t3 = (f16)__fmul_rn(sa_p, (float)x0);
-    return (f16)__fadd_rn((float)t3, (float)dir);
+    // every fp32 result passes through an opaque register before it is rounded to fp16: hipcc otherwise fuses "multiply, then
+    // round" into v_fma_mix{lo,hi}_f16, which rounds the exact product ONCE - a tensor library (and the oracle) rounds twice,
+    // fp32 then fp16 (measured on the device: differences of a few fp16 ulps where the final sum cancels)
+    auto r16 = [](float v) {
+        asm volatile("" : "+v"(v));
+        return (f16)v;
+    };
+    const f16 t1 = r16(__fmul_rn(sb_t, (float)e));
+    const f16 t2 = r16(__fsub_rn((float)xh, (float)t1));
+    const f16 x0 = r16(__fdiv_rn((float)t2, sa_t));
+    const f16 dir = r16(__fmul_rn(sb_p, (float)e));
+    const f16 t3 = r16(__fmul_rn(sa_p, (float)x0));
+    return r16(__fadd_rn((float)t3, (float)dir));
 }
 
 template <bool VEC, bool CFG>
