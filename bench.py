@@ -247,8 +247,22 @@ def mixing_rooflines(device, G=15, L=64):
     ob = torch.empty_like(p0)
     us_big = _event_time_us(lambda: ops.slerp_strided(p0, p1, frb, n, out=ob), iters=5, warm=2)
     gbs = pairs * n * 6 / us_big / 1e3
+    # the figure to QUOTE is the rocprofv3-reported one of the committed run of tools/mixing_rocprof.py (kernel durations, not hipEvents
+    # around a host call); the live hipEvent number of this run is kept beside it
+    rocprof = None
+    for tag in ("r05", "r04", "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_mixing_rocprof.json")) as fh:
+                k = next(k for k in json.load(fh)["kernels"] if "slerp_strided" in k["name"])
+            rocprof = {"GB_per_s": k["GB_per_s"], "frac": k["GB_per_s"] / HBM_PEAK_GBS, "profile": f"profiles/{tag}_mixing_rocprof.json"}
+            break
+        except Exception:
+            continue
     out.append({"kernel": "slerp_strided_kernel (interpolate_spherical: parental mix / crossfeed)", "bound": "hbm",
-                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "achieved": rocprof["GB_per_s"] if rocprof else gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (rocprof["GB_per_s"] if rocprof else gbs) / HBM_PEAK_GBS,
+                "achieved_source": "rocprofv3 kernel durations (committed profile)" if rocprof else "hipEvents of this run",
+                "rocprof_reported": rocprof, "hip_events_this_run": {"GB_per_s": gbs, "frac": gbs / HBM_PEAK_GBS},
                 "algorithmic_bytes_per_element": 6, "batch": {"pairs": pairs, "elements_per_pair": n, "us": us_big},
                 "native_launch": {"pairs": G, "elements_per_pair": n, "us": us_native,
                                   "note": "one launch per denoising step of the wavefront: launch-latency bound"}})
@@ -278,9 +292,11 @@ def roofline_blocks(prof, launch_counts, device):
         "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
         "traffic": _pmc_traffic_per_launch()[0],
         "traffic_measured_at": _pmc_traffic_per_launch()[1],
-        "feed_note": "GEMM main loops on this chip are bounded by operand delivery before the matrix pipe: with the arithmetic "
-                     "taken away 256 CUs receive 38-50 GB/s each in GEMM-like sharing patterns (tools/probes/feed_rate.cpp, "
-                     "profiles/r04_feed_rate.txt) = 1.26-1.65 PFLOP/s for 256x256x64 tiles, 0.85-1.1 for 256x128, 0.4 for 64x64",
+        "headroom_note": "like-for-like against the vendor library (rocBLAS gemm_ex, no epilogue operands on either side; "
+                         "profiles/r05_gemm_bench_call4.txt): at or ahead of it on 7 of the 10 program shapes, 12-18 % behind on "
+                         "M 4352 x N 1280 / 3840 at K 1280 / 2560 (its stream-K tiles balance 230 tiles over 256 CUs); PMC of the halo conv "
+                         "(profiles/r05_halo_pmc_lean_epilogue.json): matrix pipe 51 % busy on the VAE's big shapes, 65 % on the UNet's "
+                         "deep-K shape, 0.5 LDS instructions per MFMA, LDS pipe 25 % busy - wave time goes to vmcnt / barrier waits",
         "traffic_unit": "HBM-side bytes per GEMM/conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                         "command committed in profiles/; null if absent)",
         "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
@@ -324,7 +340,7 @@ def roofline_blocks(prof, launch_counts, device):
 def _pmc_traffic_per_launch():
     """HBM traffic of the GEMM family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), per launch
     like `achieved`, and where that was measured (profile file, commit); PMC collection cannot run inside the timed bench."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")
         try:
             with open(path) as fh:
@@ -450,7 +466,9 @@ def cpu_baseline(unet_w, vae_w, census):
             out.update({"value": len(frames) / dt, "measured": True, "seconds": dt, "frames": len(frames),
                         "unet_forwards": o.unet.calls, "vae_decodes": o.vae.calls,
                         "sample": f"cfg 2 RUN once, not extrapolated: {len(frames)} frames in {dt:.1f} s ({o.unet.calls} UNet forwards, "
-                                  f"{o.vae.calls} decodes) through the engine's host layer on the CPU fp32 oracle pipe; " + samples})
+                                  f"{o.vae.calls} decodes) through THIS REPO's host layer (latentblending_amd.BlendingEngine; the reference's "
+                                  f"own host classes cannot run here: /root/reference does not exist on the GPU box) on the CPU fp32 "
+                                  f"oracle pipe; " + samples})
         except Exception as exc:
             out["run_error"] = repr(exc)
         finally:
