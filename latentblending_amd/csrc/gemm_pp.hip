@@ -31,13 +31,13 @@
 //   WAR: load segment p requests into the slot of half-tile p - 2, last read in a phase <= p - 2, i.e. in an EARLIER interval
 //        for both groups; reads issued at the end of an interval are waited for by their own wave before it computes.
 //
-// What bounds it (tools/probes/feed_rate.cpp, profiles/r04_feed_rate.txt): with the arithmetic taken away, 256 blocks
-// streaming half-tiles in GEMM-like sharing patterns receive 38 GB/s per CU (1 x 32 strips) to 50 GB/s (4 x 8 / 8 x 4
-// patches) whatever the depth beyond 4 half-tiles, the staging instruction or the row stride - one 256 x 256 x 64 tile every
-// 1.3-1.7 us = 1.26-1.65 PFLOP/s.  This loop runs at 1.3-1.4 PFLOP/s on 8192^3 (the vendor library's stream-K kernels:
-// 1.46-1.51); variants with a deeper ring (10 slots / 8 ahead), a shallower one (4 ahead), two barriers per phase, the
-// requests inside the compute segments, and a one-wave-per-SIMD 4 x (128 x 128) form were built, verified and measured - none
-// beat this one (profiles/r04_gemm_bench_call*.txt, git history).
+// Where it stands (profiles/r04_gemm_bench_call*.txt, r05_gemm_bench_call4.txt): 1.3-1.4 PFLOP/s on 8192^3 against 1.46-1.51 for the
+// vendor library's stream-K kernels (hand-scheduled Tensile assembly, 256x240 / 224x224 macro tiles); on the programs' shapes at or
+// ahead of the library except where the grid is one partial round.  Variants with a deeper ring (10 slots / 8 ahead), a shallower
+// one (4 ahead), two barriers per phase, the requests inside the compute segments, and a one-wave-per-SIMD 4 x (128 x 128) form were
+// built, verified and measured - none beat this one (git history).  (The round-4 header derived a ceiling for this tile from the
+// operand-feed probe tools/probes/feed_rate.cpp; that probe streams private panels per XCD and is HBM-bound by construction - the
+// vendor kernels exceed its "strip" row - so the claim is withdrawn.)
 // LayerNorm folding (LB_GEMM_LN_A) is NOT offered here: two forms were built and verified (row statistics by v_dot2 on the A
 // fragments inside the compute segments; and split over the four wave columns, inside the load segments) and cost the
 // loop +40 % / +19 % on the GEGLU projection and +28 % / +17 % on q|k|v - more than the 8.7 us LayerNorm launch they
