@@ -454,10 +454,8 @@ class StableDiffusionXLPipeline:
             with torch.cuda.stream(side):
                 ctx, pooled = conditioning(conds)
                 ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
-                prog.set_conditioning(ctx, pooled, ids)
-                for t in (ctx, pooled, ids):    # (allocated on the side stream, read by launches of the main stream later)
-                    t.record_stream(torch.cuda.current_stream())
-                return prog, side.record_event()
+                prog.set_conditioning(ctx, pooled, ids)     # (copies into program-owned buffers, then the conditioning program: all
+                return prog, side.record_event()            # on `side` - the temporaries above never meet another stream)
 
         # G == 0: a farm rank that owns no mid branch of the round (fewer gaps than ranks) still runs both anchors
         dead = [bool(elide_dead_steps) and G > 0 and i >= idx_injection and i + 1 < steps and
