@@ -130,13 +130,7 @@ typedef struct LbGemmParams {
     float* ch_stats;         /* LB_GEMM_CH_STATS: output [N][row blocks] float2 (sum, sum of squares), else unused */
     int ch_stats_rows;       /* LB_GEMM_CH_STATS: row blocks per channel the caller's buffer holds = B * lb_gemm_ch_stat_rows();
                               * the launcher refuses any other value (the kernel's layout and the buffer cannot drift apart) */
-    int* tickets;            /* optional, with `partial`: LB_GEMM_TICKETS (1024) ints, ZERO when first used and left zero by every
-                              * launch.  Given, a split-K launch of the direct-to-LDS family sums its slabs INSIDE the launch (every
-                              * slice writes its fp32 slab write-through and draws a ticket of its tile; the last arriver sums the
-                              * slabs in slab order - deterministic - and runs the tile epilogue) instead of a second reduce launch.
-                              * One array per stream of launches: launches that may run concurrently must not share it */
 } LbGemmParams;
-#define LB_GEMM_TICKETS 1024
 
 int lb_gemm_f16(const LbGemmParams* params, void* stream);
 long lb_gemm_workspace_bytes(int M, int N);
@@ -168,7 +162,6 @@ int lb_gemm_ch_stat_rows(const LbGemmParams* params);
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
 void lb_gemm_set_wide_store(int on);              /* tuning: 1 = 16-byte epilogue stores for fp16 row-major outputs (same results) */
-void lb_gemm_set_fused_splitk(int on);            /* tuning: 1 (default) = split-K launches given LbGemmParams.tickets reduce in the launch, 0 = always the reduce launch */
 void lb_gemm_set_lean_epilogue(int on);           /* tuning: 1 (default) = one-round-trip tile epilogue where it applies, 0 = the per-row form everywhere (same results) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 

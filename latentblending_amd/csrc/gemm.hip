@@ -388,16 +388,8 @@ static int default_depth(const LbGemmParams& p, int tile) {
     return 4;
 }
 
-// In-launch split-K reduction (gemm_glds.hip): 1 (default) whenever the caller gave a ticket array; 0 = always the reduce launch
-static int g_fused_splitk = 1;
-extern "C" void lb_gemm_set_fused_splitk(int on) { g_fused_splitk = on; }
-
 static int gemm_launch_impl(LbGemmParams p, int tile, int depth, int variant, int stages, dim3 grid,
                             hipStream_t stream) {
-    const bool glds = tile >= 1 && tile <= 3 && variant == 1 && p.zero_page != nullptr;     // (the 4-wave direct-to-LDS tiles implement it)
-    const bool fused = p.splitk > 1 && g_fused_splitk && p.tickets != nullptr && glds && grid.x <= LB_GEMM_TICKETS &&
-                       (long)p.splitk * p.M * p.N * 4 < (1l << 31);
-    if (fused) p.reserved2_ |= 4;       // (bit 2: the kernel sums the slabs itself; no reduce launch below)
     if (tile == 9) {
         lb_gemm_launch_pp(p, grid, stream);
     } else if (variant == 1 && p.zero_page != nullptr) {
@@ -410,7 +402,7 @@ static int gemm_launch_impl(LbGemmParams p, int tile, int depth, int variant, in
     }
     int rc = lb_check_launch("lb_gemm_f16");
     if (rc) return rc;
-    if (p.splitk > 1 && !fused) {
+    if (p.splitk > 1) {
         const long quads = (long)p.M * (p.N / 4);
         long gsz = (quads + 255) / 256;
         if (gsz > 2048) gsz = 2048;

@@ -302,8 +302,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before exit/epilogue
 
     // ---- epilogue (identical to gemm.hip) ----
-    constexpr bool FUSED_SPLITK = WMW == 2;     // (only the 4-wave tiles are ever split by the policy; the 6- / 8-wave tiles keep their registers)
-    if (p.splitk > 1 && !(FUSED_SPLITK && (p.reserved2_ & 4))) {
+    if (p.splitk > 1) {
         float* slab = p.partial + (long)blockIdx.z * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -316,60 +315,6 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
             }
         }
         return;
-    }
-    if constexpr (FUSED_SPLITK) if (p.splitk > 1) {
-        // ---- in-launch split-K reduction (round 5; p.tickets given: launcher sets bit 2 of reserved2_) --------------------------
-        // The hand-off recipe for gfx950's 8 XCDs with private, mutually incoherent L2s (cdna_hip_programming.md, "in-launch
-        // split-K reduction" / Guideline 16 R1): every slice stores its fp32 slab WRITE-THROUGH (16-byte buffer stores with sc1:
-        // the bytes leave the XCD's L2, so no release fence), every storing wave drains its stores (vmcnt(0)), one barrier, ONE
-        // lane draws the tile's ticket with a relaxed agent-scope fetch_add.  The block that draws splitk - 1 is the last arriver:
-        // it puts the ticket back to zero for the next launch (stream order separates launches), reads every slab with sc1 loads
-        // (served past its L1, which may hold nothing valid) and sums them IN SLAB ORDER - the same order whichever slice arrives
-        // last, so results are deterministic - then runs the ordinary tile epilogue.  Nobody spins: a block that is not last is
-        // done.  Replaces gemm_splitk_reduce_kernel (192 launches per transition in the B = 2 programs).
-        typedef unsigned lb_u4s __attribute__((ext_vector_type(4)));
-        const long slab_elems = (long)p.M * p.N;
-        const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)(p.splitk * slab_elems * 4), 0x00020000);
-        unsigned off[TM][TN];           // byte offset of the lane's quad in slab 0; 0xffffffff = outside the problem
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wave_m * WROWS + i * 16 + l16;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wave_n * (BN / 2) + j * 16 + 4 * g;
-                off[i][j] = (m < p.M && n < p.N) ? (unsigned)(((long)m * p.N + n) * 4) : 0xffffffffu;
-            }
-        }
-        const unsigned zoff = (unsigned)(blockIdx.z * slab_elems * 4);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                if (off[i][j] != 0xffffffffu)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lb_u4s, acc[i][j]), ws, zoff + off[i][j], 0, /*sc1*/ 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave drains its write-through stores ...
-        __syncthreads();                                        // ... before the one ticket of the block is drawn
-        int* const flag = reinterpret_cast<int*>(lds);          // (the staging ring is dead: reuse its first word)
-        if (tid == 0) flag[0] = __hip_atomic_fetch_add(p.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (flag[0] != p.splitk - 1) return;                    // (block-uniform)
-        if (tid == 0) __hip_atomic_store(p.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-        for (int z = 0; z < p.splitk; ++z) {
-            const unsigned zo = (unsigned)(z * slab_elems * 4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const unsigned o = off[i][j] != 0xffffffffu ? zo + off[i][j] : 0u;      // (masked lanes read slab 0's first quad: never stored)
-                    acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, o, 0, /*sc1*/ 16));
-                }
-        }
-        // (falls through to the tile epilogue below with the summed accumulators)
     }
     if (LNA) {
         // every lane ends with the statistics of its own TM output rows: fold the four k-slices (g = 0..3) of a row

@@ -33,7 +33,6 @@ class LbGemmParams(C.Structure):
         ("splitk", C.c_int), ("zero_page", C.c_void_p),
         ("scatter", C.c_int), ("sc_py", C.c_int), ("sc_px", C.c_int), ("reserved_", C.c_int),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("reserved2_", C.c_int), ("ch_stats", C.c_void_p), ("ch_stats_rows", C.c_int),
-        ("tickets", C.c_void_p),
     ]
 
 
@@ -48,7 +47,6 @@ class LbAttnParams(C.Structure):
 
 GEMM_OUT_F32, GEMM_RES_F32, GEMM_GEGLU, GEMM_TRANS_OUT, GEMM_SILU, GEMM_RELU, GEMM_LN_A = 1, 2, 4, 8, 16, 32, 64
 GEMM_QUICK_GELU, GEMM_GELU, GEMM_CH_STATS = 128, 256, 512
-GEMM_TICKETS = 1024          # ints a split-K ticket array holds (include/lb_hip.h: LB_GEMM_TICKETS)
 
 _vp, _i, _l, _f, _d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -74,7 +72,6 @@ SIGNATURES = {
     "lb_gemm_set_variant": (None, [_i, _i]),
     "lb_gemm_set_wide_store": (None, [_i]),
     "lb_gemm_set_lean_epilogue": (None, [_i]),
-    "lb_gemm_set_fused_splitk": (None, [_i]),
     "lb_gemm_pp_set_group": (None, [_i]),
     "lb_gemm_set_pp_auto": (None, [_i]),
     "lb_gemm_set_halo": (None, [_i]),
@@ -130,7 +127,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_set_lean_epilogue", "lb_gemm_set_fused_splitk", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_set_lean_epilogue", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

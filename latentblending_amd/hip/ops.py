@@ -160,18 +160,6 @@ def subpixel_upsample_weights(w: torch.Tensor, cin_pad: Optional[int] = None):
     return out
 
 
-_TICKETS = {}
-
-
-def split_tickets(device) -> torch.Tensor:
-    """The ticket words of the in-launch split-K reduction for eager calls on ``device`` (zero, and left zero by every launch)."""
-    key = torch.device(device).index
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(lib.GEMM_TICKETS, dtype=torch.int32, device=device)
-    return t
-
-
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None, rows_per_batch=0,
          flags: int = 0, alpha: float = 1.0, out: Optional[torch.Tensor] = None, splitk_ws: bool = True,
          conv: Optional[dict] = None, M: Optional[int] = None, ln=None, ch_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -231,7 +219,6 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, residual=None, rowvec=None
     if splitk_ws and not (flags & lib.GEMM_GEGLU) and ln is None:
         ws = torch.empty(api.lb_gemm_workspace_bytes(Mv, N) // 4, dtype=F32, device=dev)
         p.partial = ws.data_ptr()
-        p.tickets = split_tickets(dev).data_ptr()
     if conv is not None and conv.get("halo"):         # experimental halo-tile 3x3 kernel (csrc/conv3_halo.hip)
         api.lb_conv3x3_halo_f16(C.byref(p), stream_ptr())
     else:

@@ -142,9 +142,6 @@ class Emitter:
         self.norm_log: List[dict] = []      # GroupNorm / LayerNorm launches: algorithmic HBM bytes
         self._retired: List[torch.Tensor] = []
         self.zero_page = torch.zeros(64, dtype=torch.uint8, device=self.device)
-        # ticket words of the in-launch split-K reduction: zero now, left zero by every launch; one array per program (the ops of
-        # a program run in stream order; programs that overlap on different streams each have their own Emitter)
-        self.tickets = torch.zeros(lib.GEMM_TICKETS, dtype=torch.int32, device=self.device)
 
     # -- workspaces -------------------------------------------------------------------------
     def _gemm_ws(self, M: int, N: int) -> Optional[torch.Tensor]:
@@ -207,8 +204,6 @@ class Emitter:
             p.ch_stats, p.ch_stats_rows = ch_stats.data_ptr(), ch_stats.shape[1]    # [N][B * rows][2]: checked by the launcher
         if splitk and not (flags & lib.GEMM_GEGLU) and ln is None:
             p.partial = _p(self._gemm_ws(M, N))
-            if p.partial:
-                p.tickets = self.tickets.data_ptr()
         api.lb_gemm_f16(C.byref(p), _stream())
         mult = 4.0 if p.scatter == 2 else 1.0          # (four parities: four times the rows, weights and outputs)
         self.gemm_log.append({"M": M, "N": N, "K": K, "flops": mult * 2.0 * M * N * K, "conv": conv is not None,

@@ -311,35 +311,6 @@ def test_gemm_splitk(splitk, results_log):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3])
-@pytest.mark.parametrize("shape,splitk", [((512, 1280, 5120), 4), ((300, 260, 1280), 3), ((512, 1280, 1280), 16), ((2048, 640, 5760), 4)])
-def test_gemm_splitk_reduced_in_the_launch(shape, splitk, tile, results_log):
-    """Round 5: a split-K launch given a ticket array sums its fp32 slabs INSIDE the launch (write-through slabs, one ticket per
-    tile, the last-arriving slice reduces in slab order and runs the tile epilogue) instead of gemm_splitk_reduce_kernel.  Against
-    the fp32 reference; DETERMINISTIC - ten launches (the arrival order of the slices varies) give the same bits; the ticket words
-    are zero again after every launch; and within rounding of the two-launch form (whose reduce kernel adds bias / residual in another
-    order).  Ragged M / N, uneven slices (20 K-tiles / 3), every 4-wave tile of the direct-to-LDS family."""
-    o, l = ops(), lib()
-    M, N, K = shape
-    A, W = rnd(M, K, seed=331).to(DEV), rnd(N, K, seed=332, scale=K ** -0.5).to(DEV)
-    bias, res = rnd(N, seed=333, dtype=torch.float32).to(DEV), rnd(M, N, seed=334).to(DEV)
-    ref = A.float() @ W.float().t() + bias + res.float()
-    tickets = o.split_tickets(DEV)
-    l.api.lb_gemm_set_tuning(tile, splitk)
-    try:
-        runs = [o.gemm(A, W, bias=bias, residual=res) for _ in range(10)]
-        assert int(tickets.abs().max()) == 0
-        l.api.lb_gemm_set_fused_splitk(0)
-        two_launch = o.gemm(A, W, bias=bias, residual=res)
-    finally:
-        l.api.lb_gemm_set_fused_splitk(1)
-        l.api.lb_gemm_set_tuning(0, 0)
-    check_close(results_log, f"gemm_splitk_in_launch_{M}x{N}x{K}_k{splitk}_t{tile}", runs[0], ref)
-    for r in runs[1:]:
-        assert torch.equal(r, runs[0])
-    assert (runs[0].float() - two_launch.float()).abs().max().item() <= 2 ** -9 * ref.abs().max().item()
-
-
-@pytest.mark.parametrize("tile", [1, 2, 3])
 def test_gemm_geglu(tile, results_log):
     o, l = ops(), lib()
     M, C = 300, 640
