@@ -608,10 +608,49 @@ def secondary_lines(pipe, args, branches):
         out.append({"name": "cfg3: SDXL base 1024x1024, 30 steps, guidance 4.0 (CFG), depth_strength 0.5, nmb_max_branches 15",
                     "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "frames": n,
                     "levels": [int(v) for v in be.list_idx_injection], "stems": [int(v) for v in be.list_nmb_stems]})
+        # BASELINE configs[4] at FULL width on this one GPU: example_multi_trans.py:17-58 with 6 prompts on the base model (1024^2, 30 steps,
+        # depth_strength 0.5, 15 branches per transition, negative prompt, swap_forward + recycle_img1; LPIPS-driven insertion) - the
+        # programs of this shape were recorded by the cfg-3 line above; ONE pass, five transitions
+        try:
+            from latentblending_amd import replay
+            be5 = BlendingEngine(base_pipe, do_compile=not args.no_graphs, frontier_width=args.frontier, verbose=False)
+            be5.host_frames = True
+            be5.set_negative_prompt("blurry, pale, low-res, lofi")
+            be5.set_branching(depth_strength=0.5, nmb_max_branches=15)
+            prompts6 = ["lake and forest", "alien desolate landscapes", "psychedelic skyscraper city", "a reef at dawn", "fog over a harbour",
+                        "desert under two moons"]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            segs = replay.run_multi_transition(be5, prompts6, [420, 421, 977, 12, 90001, 5], None)
+            for seg in segs:
+                materialise_frames(seg)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            nfr = sum(len(s_) for s_ in segs)
+            out.append({"name": "cfg5 at full width on ONE GPU: SDXL base 1024x1024, 30 steps, 6-prompt multi-transition (5 transitions, swap_forward + "
+                                "recycle_img1), depth_strength 0.5, 15 branches each, negative prompt", "value": nfr / dt, "unit": "frames/s",
+                        "seconds": dt, "frames": nfr, "transitions": len(segs), "ms_per_transition": dt * 1e3 / max(len(segs), 1)})
+            del be5
+        except Exception as exc:
+            out.append({"name": "cfg5 at full width", "error": repr(exc)})
         del be, base_pipe
         torch.cuda.empty_cache()
     except Exception as exc:
         out.append({"name": "cfg3", "error": repr(exc)})
+    try:    # BASELINE configs[3] at FULL width on this one GPU: SDXL-Turbo 512^2, 4 steps, 64 branches as ONE frontier of 64 (what an
+        # 8-GPU farm shards): 2 x B=2 + 2 x B=66 UNet steps, 66 decodes in batches of keyframe_chunk
+        be = BlendingEngine(pipe, do_compile=not args.no_graphs, frontier_width=64, verbose=False)
+        be.host_frames = True
+        be.set_prompt1("photo of underwater landscape, fish, und the sea, incredible detail, high resolution")
+        be.set_prompt2("rendering of an alien planet, strange plants, strange creatures, surreal")
+        be.set_branching(nmb_max_branches=64)
+        n, dt = timed(be, 2, 1)
+        out.append({"name": "cfg4 at full width on ONE GPU: SDXL-Turbo 512x512, 4 steps, nmb_max_branches 64, frontier 64", "value": n / dt,
+                    "unit": "frames/s", "ms_per_step": dt * 1e3, "frames": n, "frontier_rounds": be.stats.get("frontier_rounds", 0) / 2})
+        del be
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out.append({"name": "cfg4 at full width", "error": repr(exc)})
     return out
 
 
