@@ -90,6 +90,10 @@ def test_cfg4_stated_tree_native_frontier64_matches_oracle_engine(results_log):
     op = OP.StableDiffusionXLPipeline(turbo=True, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
     lp = R.OracleLPIPS(7)
     set_backend(R.TorchCpuBackend())
+    import os
+    import torch
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))          # (tiny-width CPU oracle: hundreds of host threads only slow it down)
     try:
         np.random.seed(0)
         ob = BlendingEngine(op, metric=lp, verbose=False, frontier_width=64)
@@ -99,6 +103,7 @@ def test_cfg4_stated_tree_native_frontier64_matches_oracle_engine(results_log):
         want = ob.run_transition(fixed_seeds=[420, 421])
     finally:
         set_backend(None)
+        torch.set_num_threads(threads)
     assert [float(f) for f in ob.tree_fracts] == [float(f) for f in be.tree_fracts] == c["tree_fracts"]
     assert be.stats.get("frontier_rounds", 0) == ob.stats.get("frontier_rounds", 0)
     sims, osims = np.array([float(x) for x in be.tree_similarities]), np.array([float(x) for x in ob.tree_similarities])

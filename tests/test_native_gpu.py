@@ -219,8 +219,13 @@ def test_transition_with_ddim_scheduler_matches_oracle(frontier, results_log):
         be.set_prompt1("photo of a reef")
         be.set_prompt2("rendering of an alien planet")
     set_backend(R.TorchCpuBackend())
-    imgs_o = be_o.run_transition(fixed_seeds=[420, 421])
-    set_backend(None)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))          # (tiny-width CPU oracle)
+    try:
+        imgs_o = be_o.run_transition(fixed_seeds=[420, 421])
+    finally:
+        torch.set_num_threads(threads)
+        set_backend(None)
     imgs_p = be_p.run_transition(fixed_seeds=[420, 421])
     assert len(imgs_o) == len(imgs_p) and be_o.tree_fracts == be_p.tree_fracts and be_o.tree_idx_injection == be_p.tree_idx_injection
     lat_err = max(rel_l2(a[-1], b[-1]) for a, b in zip(be_p.tree_latents, be_o.tree_latents))
