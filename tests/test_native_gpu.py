@@ -196,7 +196,7 @@ def test_transition_tree_matches_oracle(turbo, results_log):
 def test_transition_with_ddim_scheduler_matches_oracle(frontier, results_log):
     """The whole branched transition with DDIM (eta 0) on both sides - NativeSDXLPipe(scheduler="ddim") through the native
     batched loops (lb_ddim_step_f16; the scale launch is the identity) against the engine on the CPU oracle pipe carrying the
-    oracle's DDIMScheduler under the generic step-by-step loop: base model, 6 steps, guidance 3.0 (CFG), two injection levels."""
+    oracle's DDIMScheduler under the generic step-by-step loop: base model, 4 steps, guidance 3.0 (CFG), two injection levels."""
     import dataclasses as dc
     from latentblending_amd import BlendingEngine
     from latentblending_amd.backend import set_backend
@@ -213,9 +213,9 @@ def test_transition_with_ddim_scheduler_matches_oracle(frontier, results_log):
     be_p = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=frontier)
     for be in (be_o, be_p):
         be.set_dimensions((128, 128))
-        be.set_num_inference_steps(6)
+        be.set_num_inference_steps(4)
         be.set_guidance_scale(3.0)
-        be.set_branching(depth_strength=0.5, nmb_max_branches=6)
+        be.set_branching(depth_strength=0.5, nmb_max_branches=5)
         be.set_prompt1("photo of a reef")
         be.set_prompt2("rendering of an alien planet")
     set_backend(R.TorchCpuBackend())
