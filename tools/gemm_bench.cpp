@@ -7,7 +7,7 @@
 //   * the vendor library (rocBLAS gemm_ex, fp16 in / fp32 accumulate) on the same operands, to size the head-room.
 // Build (cross-compiles here):  hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/gemm_bench.cpp -I include
 //        -L latentblending_amd/hip -llbhip -lrocblas -Wl,-rpath,'$ORIGIN/../../latentblending_amd/hip' -o tools/build/gemm_bench
-// Usage: tools/build/gemm_bench [set] [rounds]      set = b17 | b2 | big | all
+// Usage: tools/build/gemm_bench [set] [rounds]      set = b17 | b2 | big | all | ksweep
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <rocblas/rocblas.h>
@@ -53,6 +53,14 @@ static const Shape B2[] = {
     {2048, 640, 640, 0, 2, "attn out 640 (40)"},
     {2048, 5120, 640, 1, 1, "ff GEGLU 640"},
 };
+// K sweep of the most frequent projection (no epilogue operands): per-K-tile slope and fixed cost of a launch, ours and the vendor's
+static const Shape KSWEEP[] = {
+    {4352, 1280, 640, 0, 0, "K sweep: 10 K-tiles"},
+    {4352, 1280, 1152, 0, 0, "K sweep: 18 K-tiles"},
+    {4352, 1280, 1280, 0, 0, "K sweep: 20 K-tiles"},
+    {4352, 1280, 1920, 0, 0, "K sweep: 30 K-tiles"},
+    {4352, 1280, 2560, 0, 0, "K sweep: 40 K-tiles"},
+};
 static const Shape BIG[] = {
     {8192, 8192, 8192, 0, 0, "8192^3"},
     {4096, 4096, 4096, 0, 0, "4096^3"},
@@ -77,7 +85,8 @@ int main(int argc, char** argv) {
     if (set == "b17" || set == "all") shapes.insert(shapes.end(), std::begin(B17), std::end(B17));
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
-    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t1", 1, 1, 8}};
+    if (set == "ksweep") shapes.insert(shapes.end(), std::begin(KSWEEP), std::end(KSWEEP));
+    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t7", 7, 1, 8}, {"t1", 1, 1, 8}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
     {
