@@ -460,9 +460,11 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
                 const long cur = tile == 5 ? rounds5 * 174 : rounds4 * 100;
                 if (b192 >= 160 && rounds7 * 78 < cur) tile = 7;
             }
-            // ... except the one case where it did win in that measurement (24.9 vs 26.5 us): a short-K GEMM whose 256x128
-            // grid is a single partial round (the UNet's 192 M = 4352, N = 1280, K = 1280 projections per forward).
-            if (!(g_policy_off & 64) && !geglu && !p.conv && tile == 4 && n_fits && p.K <= 1536 && b256 < 224) {
+            // ... except where it did win in that measurement (24.9 vs 26.5 us): a GEMM whose 256x128 grid is a single partial
+            // round (M = 4352, N = 1280: 170 blocks, 230 of 192x128).  Round 5 (profiles/r05_gemm_tile7_vs_auto.txt, with the
+            // one-round-trip epilogue): it wins there at every K - K 1280: 24.2 vs 26.2 us, K 2560: 37.2 vs 39.0, K 5120 (the
+            // feed-forward output projection, 60 per forward): 71.9 vs 73.7 - so the K <= 1536 condition of rounds 2-4 is gone.
+            if (!(g_policy_off & 64) && !geglu && !p.conv && tile == 4 && n_fits && b256 < 224) {
                 const long b192 = blocks(192, 128);
                 if (b192 <= 256 && b192 * 10 >= b256 * 13) tile = 7;
             }
