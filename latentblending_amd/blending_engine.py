@@ -634,7 +634,7 @@ class BlendingEngine:
                                          [(m, fl, fr) for (fl, fr, m) in gaps])
         ready = {(fl, fr): dict(fract=m, traj=traj, frame=frame_at[m], sl=sims[k][0], sr=sims[k][1])
                  for k, ((fl, fr, m), traj) in enumerate(zip(gaps, mids))}
-        self.guidance_scale = self.dh.guidance_scale = guid[-1]
+        # (the guidance scale this transition leaves behind is set where the branches are COMMITTED: _grow_level_frontier)
         self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
         self.stats["speculation_evaluated"] = self.stats.get("speculation_evaluated", 0) + len(gaps)
         return first, last, ready
@@ -655,6 +655,7 @@ class BlendingEngine:
         tree = self._tree
         ready = dict(ready) if ready else {}     # (f_left, f_right) -> dict(fract, traj, frame, sl, sr)
         remaining = stems
+        last_committed = None                    # fraction of the branch the greedy order committed last at this level
         ratio_l, ratio_r = [], []                # measured (child-to-left-end, child-to-right-end) distance / parent gap distance
 
         def learn(key, r, parent):               # one sample per evaluated child whose parent gap distance is known
@@ -680,6 +681,7 @@ class BlendingEngine:
                     r = ready.pop(key)
                     learn(key, r, tree.similarities[gap])
                     tree.commit(r["fract"], idx_injection, r["traj"], r["frame"], r["sl"], r["sr"])
+                    last_committed = r["fract"]
                     remaining -= 1
                     progressed = True
             if remaining == 0:
@@ -757,10 +759,15 @@ class BlendingEngine:
             for k, (s, (traj, frame)) in enumerate(zip(specs, results)):
                 ready[(s["left"], s["right"])] = dict(fract=s["fract"], traj=traj, frame=frame,
                                                       sl=sims[k][0], sr=sims[k][1])
-            self.guidance_scale = self.dh.guidance_scale = specs[-1]["guidance"]
             self.stats["frontier_rounds"] = self.stats.get("frontier_rounds", 0) + 1
             self.stats["speculation_evaluated"] = self.stats.get("speculation_evaluated", 0) + len(specs)
         self.stats["speculation_dropped"] = self.stats.get("speculation_dropped", 0) + len(ready)
+        # What the reference's loop leaves behind (blending_engine.py:358-362 of the reference: set_guidance_mid_dampening runs
+        # right before every branch it commits, :155-164): the dampened scale of the LAST COMMITTED branch - not of the last
+        # spec evaluated (the evaluation order of a batched round is best-first over real + virtual gaps, the commit order is
+        # the greedy one).  The next transition's anchors are denoised under this value (compute_latents1 / 2, :370-423).
+        if last_committed is not None:
+            self.set_guidance_mid_dampening(last_committed)
 
     def _gap_child_distances(self, triples, fracts):
         """[(child frame, left neighbour, right neighbour)], [(f_child, f_left, f_right)] -> [(d_left, d_right)].

@@ -25,6 +25,9 @@ Fixtures
                   numpy RNG: per-gap insert counts and a checksum of every output frame (numpy 2.x arithmetic: the
                   float32 frames are blended in float64)
 
+  guidance_chain.json  (round 6) two chained SDXL-base transitions, one level 3 x 6 stems: the mid-dampened guidance scale each
+                  transition leaves behind (the LAST COMMITTED branch's) and the second transition computed under it
+
     python -m oracle.make_golden frames      # regenerate one fixture
 """
 from __future__ import annotations
@@ -393,6 +396,43 @@ def configs_fixture(ref):
     return out
 
 
+GCHAIN_PROMPTS = ["photo of a reef", "rendering of an alien planet", "fog over a harbour"]
+GCHAIN_SEEDS = [420, 421, 977]
+
+
+def guidance_chain_fixture(ref):
+    """The guidance scale a transition LEAVES BEHIND (blending_engine.py:358-362 of the reference: set_guidance_mid_dampening
+    of the last branch committed, :155-164) and what it does to the next transition's new anchor (compute_latents2 runs
+    under it, :370-423): SDXL base tiny, 6 steps, guidance 4.0, one level idx 3 x 6 stems, two chained transitions
+    (swap_forward + recycle_img1).  With 6 stems the last branch the greedy order commits (f = 0.125 / 0.375 / ... ) is NOT the
+    last one a best-first batched round evaluates, which is what round 5's frontier got wrong."""
+    p = tiny_pipe(turbo=False)
+    np.random.seed(0)
+    segs = []
+    with H.cuda_is_identity():
+        be = ref.BlendingEngine(p)
+        be.set_dimensions((128, 128))
+        be.set_num_inference_steps(6)
+        be.set_guidance_scale(4.0)
+        be.list_idx_injection, be.list_nmb_stems = [3], [6]
+        p.noise.reset()
+        for i in range(2):
+            if i == 0:
+                be.set_prompt1(GCHAIN_PROMPTS[0])
+                be.set_prompt2(GCHAIN_PROMPTS[1])
+            else:
+                be.swap_forward()
+                be.set_prompt2(GCHAIN_PROMPTS[i + 1])
+            p.unet.calls = p.vae.calls = 0
+            imgs = be.run_transition(recycle_img1=i > 0, fixed_seeds=GCHAIN_SEEDS[i:i + 2])
+            seg = snapshot(be, imgs, p)
+            seg["guidance_scale_left_behind"] = float(be.guidance_scale)
+            seg["holder_guidance_scale"] = float(be.dh.guidance_scale)
+            segs.append(seg)
+    return {"prompts": GCHAIN_PROMPTS, "seeds": GCHAIN_SEEDS, "steps": 6, "guidance": 4.0, "list_idx_injection": [3],
+            "list_nmb_stems": [6], "segments": segs}
+
+
 def key_frames(seed, n, h, w):
     rng = np.random.RandomState(seed)
     return [rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8) for _ in range(n)]
@@ -418,7 +458,8 @@ def main():
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     only = set(sys.argv[1:])
     makers = [("planner", lambda: planner_fixture(ref)), ("slerp", lambda: slerp_fixture(ref)), ("scheduler", scheduler_fixture),
-              ("tree", lambda: tree_fixture(ref)), ("configs", lambda: configs_fixture(ref)), ("frames", lambda: frames_fixture(ref))]
+              ("tree", lambda: tree_fixture(ref)), ("configs", lambda: configs_fixture(ref)), ("frames", lambda: frames_fixture(ref)),
+              ("guidance_chain", lambda: guidance_chain_fixture(ref))]
     for name, make in makers:
         if only and name not in only:
             continue

@@ -104,3 +104,52 @@ def check_structure_cfg4_plain(be, imgs, c):
     extra = [f for f in fr if f not in grid]
     assert len(extra) == 1 and (extra[0] * 128) % 2 == 1, extra
     assert [int(i) for i in be.tree_idx_injection] == c["tree_idx_injection"]
+
+
+def gold_guidance_chain():
+    with open(os.path.join(ROOT, "tests", "golden", "guidance_chain.json")) as fh:
+        return json.load(fh)
+
+
+def run_guidance_chain(be, reset_counters=None):
+    """The calls of oracle/make_golden.py::guidance_chain_fixture on engine `be`: SDXL base, 6 steps, guidance 4.0, one level
+    idx 3 x 6 stems, two chained transitions (swap_forward + recycle_img1).  Returns [(frames, guidance left behind, holder's
+    guidance, state-dict guidance)] per transition.  The reference's loop leaves the dampened scale of the LAST COMMITTED
+    branch (/root/reference/latentblending/blending_engine.py:155-164, 358-362) and denoises the next new anchor under it
+    (:370-423)."""
+    g = gold_guidance_chain()
+    be.set_dimensions((128, 128))
+    be.set_num_inference_steps(g["steps"])
+    be.set_guidance_scale(g["guidance"])
+    be.list_idx_injection, be.list_nmb_stems = list(g["list_idx_injection"]), list(g["list_nmb_stems"])
+    out = []
+    for i in range(2):
+        if i == 0:
+            be.set_prompt1(g["prompts"][0])
+            be.set_prompt2(g["prompts"][1])
+        else:
+            be.swap_forward()
+            be.set_prompt2(g["prompts"][i + 1])
+        if reset_counters is not None:
+            reset_counters()
+        imgs = be.run_transition(recycle_img1=i > 0, fixed_seeds=g["seeds"][i:i + 2])
+        out.append((list(imgs), float(be.guidance_scale), float(be.dh.guidance_scale), float(be.get_state_dict()["guidance_scale"]),
+                    [float(f) for f in be.tree_fracts], [float(s) for s in be.tree_similarities],
+                    [float(l[-1].float().norm()) for l in be.tree_latents]))
+    return out
+
+
+def check_guidance_chain(be, runs, *, sim_rtol, norm_rtol, mean_tol, head_tol, ds_tol):
+    g = gold_guidance_chain()
+    for seg, (imgs, gs, gs_holder, gs_state, fracts, sims, norms) in zip(g["segments"], runs):
+        assert gs == gs_holder == gs_state == seg["guidance_scale_left_behind"], (gs, gs_holder, gs_state, seg["guidance_scale_left_behind"])
+        assert fracts == seg["tree_fracts"], (fracts, seg["tree_fracts"])
+        assert np.allclose(sims, seg["tree_similarities"], rtol=sim_rtol), (sims, seg["tree_similarities"])
+        for n, ref in zip(norms, seg["final_latent_norm"]):
+            assert abs(n - ref) <= norm_rtol * ref, (n, ref)
+        assert len(imgs) == seg["frames"]
+        for k, (img, mean, head, ds) in enumerate(zip(imgs, seg["frame_mean"], seg["frame_head"], seg["frame_ds16"])):
+            a = np.asarray(img)
+            assert abs(float(a.mean()) - mean) <= mean_tol, (k, float(a.mean()), mean)
+            assert np.abs(a.flatten()[:24].astype(int) - np.array(head)).max() <= head_tol
+            assert float(np.abs(box16(img) - np.array(ds)).max()) <= ds_tol, k

@@ -49,6 +49,23 @@ def test_cfg3_stated_tree_native(frontier, results_log):
                                                            "sims": [float(s) for s in be.tree_similarities]}
 
 
+@pytest.mark.parametrize("frontier", [1, 8])
+def test_guidance_chain_native(frontier, results_log):
+    """tests/golden/guidance_chain.json natively: two chained SDXL-base transitions (one level 3 x 6 stems, guidance 4.0); the scale
+    left behind is the last COMMITTED branch's (3.25, reference blending_engine.py:155-164, 358-362) at every frontier width,
+    and the second transition - its new anchor denoised under that leftover scale - is the reference's."""
+    from latentblending_amd import BlendingEngine
+    from _baseline_cfgs import check_guidance_chain, run_guidance_chain
+    p, tape = native_pipe(False)
+    np.random.seed(0)
+    be = BlendingEngine(p, verbose=False, do_compile=True, frontier_width=frontier)
+    tape.reset()
+    runs = run_guidance_chain(be)
+    assert [r[1] for r in runs] == [3.25, 3.25]
+    check_guidance_chain(be, runs, **GPU_TOL)
+    results_log[f"guidance_chain_frontier{frontier}"] = {"left_behind": [r[1] for r in runs]}
+
+
 def native_spread_metric(pipe, c):
     return spread_metric(c, lambda a, b: pipe.native_frame_distances([(a, b)])[0])
 

@@ -83,6 +83,40 @@ def test_branch_farm_reproduces_sequential_tree(run, world, tmp_path):
         assert r["sims"] == res[0]["sims"] and r["latent_sha"] == res[0]["latent_sha"] and r["frame_sha"] == res[0]["frame_sha"]
 
 
+def _guidance_chain_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pipe as OP, sdxl_ref as R
+    from latentblending_amd import BlendingEngine
+    from latentblending_amd.backend import set_backend
+    from latentblending_amd.dist import BranchFarm
+    from _baseline_cfgs import check_guidance_chain, run_guidance_chain
+    set_backend(R.TorchCpuBackend())
+    p = OP.StableDiffusionXLPipeline(turbo=False, unet_cfg=R.tiny_unet_cfg(), vae_cfg=R.tiny_vae_cfg())
+    np.random.seed(0)
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=8, farm=BranchFarm())
+    p.noise.reset()
+    runs = run_guidance_chain(be)
+    check_guidance_chain(be, runs, sim_rtol=2e-3, norm_rtol=2e-3, mean_tol=0.25, head_tol=2, ds_tol=0.5)
+    json.dump({"guidance": [r[1] for r in runs]}, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_branch_farm_leaves_the_last_committed_branchs_guidance(tmp_path):
+    """tests/golden/guidance_chain.json under a world-2 farm at frontier 8: both ranks leave 3.25 behind after each of the two
+    chained base-model transitions and compute the reference's second transition (round 5 left the last EVALUATED spec's 3.75)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_guidance_chain_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert json.load(open(tmp_path / f"rank{r}.json"))["guidance"] == [3.25, 3.25]
+
+
 def _cfg4_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -236,6 +236,27 @@ def test_engine_reproduces_reference_transition(run, cpu_backend):
     check_against_golden_run(be, imgs, c)
 
 
+@pytest.mark.parametrize("frontier", [1, 8])
+def test_guidance_left_behind_is_the_last_committed_branchs(frontier, cpu_backend):
+    """Round-5 review, parity bug 1: a frontier round stored the guidance of the last spec EVALUATED; the reference leaves the
+    dampened scale of the last branch COMMITTED (blending_engine.py:155-164, 358-362) and computes the next transition's new
+    anchor under it (:370-423).  Fixture: the unchanged reference's chain (tests/golden/guidance_chain.json): 3.25 after both
+    transitions (round 5 at frontier 8: 3.75, and a different second transition)."""
+    from latentblending_amd import BlendingEngine
+    sys_path_tests = os.path.join(ROOT, "tests")
+    import sys
+    if sys_path_tests not in sys.path:
+        sys.path.insert(0, sys_path_tests)
+    from _baseline_cfgs import check_guidance_chain, run_guidance_chain
+    p = tiny_pipe(turbo=False)
+    np.random.seed(0)
+    be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=frontier)
+    p.noise.reset()
+    runs = run_guidance_chain(be)
+    assert [r[1] for r in runs] == [3.25, 3.25]
+    check_guidance_chain(be, runs, sim_rtol=2e-3, norm_rtol=2e-3, mean_tol=0.25, head_tol=2, ds_tol=0.5)
+
+
 @pytest.mark.skipif(not H.reference_available(), reason="/root/reference not mounted")
 def test_live_differential_against_unchanged_reference(cpu_backend):
     """When the reference is mounted: run it and our engine side by side, including swap_forward +
