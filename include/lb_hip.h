@@ -162,6 +162,7 @@ int lb_gemm_ch_stat_rows(const LbGemmParams* params);
 int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
 void lb_gemm_set_wide_store(int on);              /* tuning: 1 = 16-byte epilogue stores for fp16 row-major outputs (same results) */
+void lb_gemm_set_t192_waves8(int on);             /* tuning: 1 (default) = the 192x128 tile runs 8 waves of 48x64 (tile code 10), 0 = 6 waves of 64x64 (tile code 7); same results */
 void lb_gemm_set_lean_epilogue(int on);           /* tuning: 1 (default) = one-round-trip tile epilogue where it applies, 0 = the per-row form everywhere (same results) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
@@ -183,6 +184,7 @@ int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* b
                       int x_is_f32, void* stream);
 int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int M, int C,
                      int ldx, int ldy, float eps, void* stream);
+void lb_layernorm_set_form(int form);   /* testing: 1 (default) = all loads of a row in flight + permlane / DPP reductions (round 6), 0 = the round-1 kernel; bit-identical results */
 
 /* ---- attention (AttnProcessor2_0 / scaled_dot_product_attention inside the UNet call at
  *      diffusers_holder.py:336; VAE mid-block attention at :135) ------------------------ */

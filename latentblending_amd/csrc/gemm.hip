@@ -316,6 +316,12 @@ static int g_pp_auto = 1;          // 0: the automatic policy never picks the pi
 extern "C" void lb_gemm_set_pp_auto(int on) { g_pp_auto = on; }
 static int g_force_tile = 0;      // 0 auto, else 1=128x128 2=128x64 3=64x64, direct-to-LDS only: 4=256x128 5=256x256 7=192x128
 static int g_force_splitk = 0;    // 0 auto
+// 192x128 tile: 1 (default, round 6) = 8 waves x (48 x 64) - tile code 10; 0 = the 6-wave form of rounds 2-5 (3 x 2 waves of 64 x 64 - tile
+// code 7: two of the four SIMDs carry two waves, i.e. 64 MFMAs per K-tile against 32 on the other two; with 8 waves every SIMD issues 48).
+// Bit-identical (same K order per accumulator).  profiles/r06_gemm_bench_call2.txt: M 4352 x N 1280, K 1280 / 2560 / 5120 =
+// 23.4 -> 21.9, 36.2 -> 34.0, 69.5 -> 64.4 us.
+static int g_t192_waves8 = 1;
+extern "C" void lb_gemm_set_t192_waves8(int on) { g_t192_waves8 = on; }
 static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
 extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
@@ -458,7 +464,7 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
                 const long b192 = blocks(192, 128);
                 const long rounds7 = (b192 + 255) / 256;
                 const long cur = tile == 5 ? rounds5 * 174 : rounds4 * 100;
-                if (b192 >= 160 && rounds7 * 78 < cur) tile = 7;
+                if (b192 >= 160 && rounds7 * 78 < cur) tile = g_t192_waves8 ? 10 : 7;
             }
             // ... except where it did win in that measurement (24.9 vs 26.5 us): a GEMM whose 256x128 grid is a single partial
             // round (M = 4352, N = 1280: 170 blocks, 230 of 192x128).  Round 5 (profiles/r05_gemm_tile7_vs_auto.txt, with the
@@ -466,11 +472,11 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
             // feed-forward output projection, 60 per forward): 71.9 vs 73.7 - so the K <= 1536 condition of rounds 2-4 is gone.
             if (!(g_policy_off & 64) && !geglu && !p.conv && tile == 4 && n_fits && b256 < 224) {
                 const long b192 = blocks(192, 128);
-                if (b192 <= 256 && b192 * 10 >= b256 * 13) tile = 7;
+                if (b192 <= 256 && b192 * 10 >= b256 * 13) tile = g_t192_waves8 ? 10 : 7;
             }
         }
     }
-    if (tile >= 4 && tile < 9 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;
+    if (tile >= 4 && tile != 9 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;
     // Ping-pong 256x256 loop (gemm_pp.hip): 1.15-1.27x the lock-step 8-wave tiles wherever 256-wide tiles fill the chip and
     // the K loop is long enough to pay for its deeper prologue - on the B = 17 programs the GEGLU projections (M 4352 /
     // 17408), the fused q|k|v projection, the 640-wide feed-forward output and the per-branch context projection
@@ -489,8 +495,8 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         const long b64 = blocks(64, 64);
         if (b64 > 256 && b64 <= 640 && blocks(128, 64) <= 256) tile = 2;
     }
-    const int bm = tile == 7 ? 192 : (tile >= 4 ? 256 : (tile == 3 ? 64 : 128));
-    const int bn = (tile == 5 || tile == 9) ? 256 : ((tile == 1 || tile == 4 || tile == 7) ? 128 : 64);
+    const int bm = (tile == 7 || tile == 10) ? 192 : (tile >= 4 ? 256 : (tile == 3 ? 64 : 128));
+    const int bn = (tile == 5 || tile == 9) ? 256 : ((tile == 1 || tile == 4 || tile == 7 || tile == 10) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
     // (LN_A: a block must see whole rows of A)
@@ -588,7 +594,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
         if (stages == 0)
-            stages = (tile == 3 || tile == 4 || tile == 7) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
+            stages = (tile == 3 || tile == 4 || tile == 7 || tile == 10) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

@@ -399,6 +399,7 @@ void lb_gemm_glds_init() {
     allow_lds<256, 128, 2, 4>(); allow_lds<256, 128, 3, 4>();
     allow_lds<256, 256, 2, 4>();
     allow_lds<192, 128, 3, 3>();
+    allow_lds<192, 128, 3, 4>();
 }
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave),
@@ -411,6 +412,7 @@ void lb_gemm_glds_init() {
 // under the ring depth nor the per-barrier episode is what bounds these loops.
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
     if (tile == 7) return launch_glds_variant<192, 128, 3, 3>(p, grid, stream);            // 3 x 42 KiB
+    if (tile == 10) return launch_glds_variant<192, 128, 3, 4>(p, grid, stream);           // 8 waves x (48 x 64): 3 x 40 KiB
     if (tile == 5) return launch_glds_variant<256, 256, 2, 4>(p, grid, stream);     // 128 KiB: two stages only
     if (tile == 4) {
         if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);

@@ -68,6 +68,28 @@ __device__ __forceinline__ float lb_wave_sum(float v) {
     return v;
 }
 
+// The same xor butterfly (32, 16, 8, 4, 2, 1: every lane ends with the same bits as lb_wave_sum - float addition commutes, so
+// "v[i] + v[partner]" does not depend on who fetched whom) without the LDS crossbar: permlane32 / permlane16 swaps for the two
+// widest stages, DPP row rotations / quad permutes for the rest (a rotation by 8, then by 4, reaches the xor partner's VALUE
+// because lanes i and i ^ 8 already agree after the stage before).  12 ds_bpermute round trips -> 6 VALU-class exchanges.
+__device__ __forceinline__ float lb_wave_sum_dpp(float v) {
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    return v;
+}
+
 __device__ __forceinline__ double lb_wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, LB_WAVE);

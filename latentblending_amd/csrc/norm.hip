@@ -398,10 +398,86 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const f16* __restrict__ 
     }
 }
 
+// Round 6: the form above waits for every 16-byte load of a row before it issues the next one (each sits in its own
+// exec-masked branch: hipcc drains vmcnt(0) per branch), fetches gamma / beta only after both reductions, and reduces through 12
+// ds_bpermute round trips - five to six dependent memory latencies per row, 11 us for the 22 MB of a B = 17 hidden state.  Here
+// every load of the row AND its gamma / beta vectors are requested up front (vector slots past C read slot 0 and are weighted
+// out), and the two reductions run on permlane / DPP exchanges.  Same per-lane summation order, same butterfly: the outputs are
+// bit-identical to layernorm_kernel's (tests/test_kernels_gpu.py compares the two).
+template <int NV>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, f16* __restrict__ y, int M, int C,
+                                                             int ldx, int ldy, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;                                   // (wave-uniform)
+    const int vecs = C >> 3;
+    f16x8 raw[NV];
+    f32x4 gm[NV][2], bt[NV][2];
+    bool ok[NV];
+    int vc[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {          // the row itself first: requests retire in order, the reductions wait for these only
+        const int v = lane + j * 64;
+        ok[j] = v < vecs;
+        vc[j] = ok[j] ? v : 0;
+        raw[j] = *reinterpret_cast<const f16x8*>(x + (long)row * ldx + vc[j] * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gm[j][0] = *reinterpret_cast<const f32x4*>(gamma + vc[j] * 8);
+        gm[j][1] = *reinterpret_cast<const f32x4*>(gamma + vc[j] * 8 + 4);
+        bt[j][0] = *reinterpret_cast<const f32x4*>(beta + vc[j] * 8);
+        bt[j][1] = *reinterpret_cast<const f32x4*>(beta + vc[j] * 8 + 4);
+    }
+    // (no branch anywhere below - a vector slot past C recomputes and re-stores vector 0 of the row with the same bits - so
+    //  hipcc has no predicated block to sink the gamma / beta requests into; the sched_barrier keeps them above the arithmetic)
+    __builtin_amdgcn_sched_barrier(0);
+    float val[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            val[j][e] = (float)raw[j][e];
+            s += ok[j] ? val[j][e] : 0.f;
+        }
+    const float mean = lb_wave_sum_dpp(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = val[j][e] - mean;
+            q += ok[j] ? d * d : 0.f;
+        }
+    const float rstd = rsqrtf(lb_wave_sum_dpp(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = (f16)((val[j][e] - mean) * rstd * gm[j][e >> 2][e & 3] + bt[j][e >> 2][e & 3]);
+        *reinterpret_cast<f16x8*>(y + (long)row * ldy + vc[j] * 8) = o;
+    }
+}
+
+static int g_ln_form = 1;       // 1 = layernorm_rows_kernel (round 6), 0 = the round-1 kernel (A/B: tools/ln_bench.py; tests compare the two)
+extern "C" void lb_layernorm_set_form(int form) { g_ln_form = form; }
+
 extern "C" int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int M,
                                 int C, int ldx, int ldy, float eps, void* stream) {
     LB_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "lb_layernorm_f16: C multiple of 8, <= 2048");
     LB_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "lb_layernorm_f16: ld multiple of 8");
-    LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s,
-                       (const f16*)x, gamma, beta, (f16*)y, M, C, ldx, ldy, eps));
+    const int form = g_ln_form;
+    const int nv = (C / 8 + 63) / 64;
+    const dim3 grid((M + 3) / 4), block(256);
+#define LB_LN_ARGS (const f16*)x, gamma, beta, (f16*)y, M, C, ldx, ldy, eps
+    if (form == 0) LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_kernel, grid, block, 0, s, LB_LN_ARGS));
+    if (nv == 1) LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_rows_kernel<1>, grid, block, 0, s, LB_LN_ARGS));
+    if (nv == 2) LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_rows_kernel<2>, grid, block, 0, s, LB_LN_ARGS));
+    if (nv == 3) LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_rows_kernel<3>, grid, block, 0, s, LB_LN_ARGS));
+    LB_DISPATCH_STMT("lb_layernorm_f16", hipLaunchKernelGGL(layernorm_rows_kernel<4>, grid, block, 0, s, LB_LN_ARGS));
+#undef LB_LN_ARGS
 }

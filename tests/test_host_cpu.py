@@ -633,8 +633,8 @@ def test_synthetic_weight_streams_are_the_same_on_both_sides():
 def test_gemm_tile_policy_is_pinned():
     """lb_gemm_plan (pure host arithmetic of the launcher): the tile / split-K choices the MI355X sweeps led to
     (profiles/r01_gemm_*.txt, tools/ab_policy.py, profiles/r04_gemm_bench_call*.txt) for the shapes the SDXL programs launch.
-    Tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, lock-step), 7 = 192x128 (6 waves),
-    9 = 256x256 ping-pong (gemm_pp.hip)."""
+    Tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, lock-step), 7 = 192x128 (6 waves, rounds 2-5),
+    9 = 256x256 ping-pong (gemm_pp.hip), 10 = 192x128 as 8 waves of 48x64 (round 6: every SIMD issues the same number of MFMAs)."""
     from latentblending_amd.hip import lib
 
     def plan(M, N, K, conv=False, geglu=False, ws=None, zero_page=True):
@@ -652,8 +652,8 @@ def test_gemm_tile_policy_is_pinned():
     # UNet at B=17 (M = 17*256 / 17*1024)
     assert plan(4352, 10240, 1280, geglu=True)[:2] == (9, 1)            # GEGLU: 256x256 ping-pong, 680 blocks
     assert plan(4352, 10240, 1280, geglu=True)[2] == 17 * 40
-    assert plan(4352, 1280, 1280) == (7, 1, 230)                        # short K, 170 blocks of 256x128 = 2/3 of the chip: 230 of 192x128
-    assert plan(4352, 1280, 5120) == (7, 1, 230)                        # ... at every K (round 5: 71.9 vs 73.7 us at K = 5120)
+    assert plan(4352, 1280, 1280) == (10, 1, 230)                       # short K, 170 blocks of 256x128 = 2/3 of the chip: 230 of 192x128
+    assert plan(4352, 1280, 5120) == (10, 1, 230)                       # ... at every K (round 5: 71.9 vs 73.7 us at K = 5120)
     assert plan(4352, 2560, 1280)[:2] == (5, 1)                         # one round of 256x256 beats two of 256x128 (170 tiles: lock-step form)
     assert plan(4352, 3840, 1280) == (9, 1, 255)                        # fused q|k|v: one round of ping-pong tiles
     assert plan(17408, 5120, 640, geglu=True)[0] == 9                   # K = 640 pays only over several rounds (1360 tiles) ...

@@ -428,8 +428,11 @@ def test_groupnorm(case, silu, results_log):
     check_close(results_log, f"groupnorm_{B}_{HW}_{C}_{int(f32_in)}_{int(silu)}", got, ref, floor=2e-3)
 
 
-@pytest.mark.parametrize("shape", [(1024, 640), (256, 1280), (77, 2048), (5, 64)])
+@pytest.mark.parametrize("shape", [(1024, 640), (256, 1280), (77, 2048), (5, 64), (4352, 1280), (131, 768), (9, 1032)])
 def test_layernorm(shape, results_log):
+    """fp32 torch reference; the round-6 kernel (every load of a row in flight, permlane / DPP reductions) must also equal the
+    round-1 kernel bit for bit (same per-lane summation order, same butterfly)."""
+    from latentblending_amd.hip.lib import api
     o = ops()
     M, C = shape
     x = rnd(M, C, seed=48, scale=3.0) + 1
@@ -437,6 +440,13 @@ def test_layernorm(shape, results_log):
     ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
     got = o.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
     check_close(results_log, f"layernorm_{M}_{C}", got, ref, floor=2e-3)
+    api.lb_layernorm_set_form(0)
+    try:
+        old = o.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    finally:
+        api.lb_layernorm_set_form(1)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), old.view(torch.int16))
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
@@ -642,9 +652,12 @@ def test_small_kernels(results_log):
 
 # ------------------------------------------------------------------ direct-to-LDS GEMM variant
 @pytest.mark.parametrize("stages", [2, 3, 4])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 10])
 def test_gemm_glds_variant(tile, stages, results_log):
-    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references."""
+    """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references.  Tile 10 (round 6) = the 192x128 tile
+    as 8 waves of 48 x 64 (three 16-row MFMA tiles per wave)."""
+    if tile in (7, 10) and stages != 3:
+        pytest.skip("the 192x128 tiles have one ring depth (3)")
     o, l = ops(), lib()
     l.api.lb_gemm_set_variant(1, stages)
     l.api.lb_gemm_set_tuning(tile, 0)
@@ -887,6 +900,24 @@ def test_gemm_pingpong_geglu_and_splitk(results_log):
         l.api.lb_gemm_set_tuning(0, 0)
 
 
+@pytest.mark.parametrize("shape", [(4352, 1280, 1280), (1000, 384, 256), (300, 260, 128)])
+def test_gemm_192x128_eight_waves_bit_identical_to_six(shape):
+    """Round 6: the 192x128 tile as 8 waves of 48 x 64 (tile code 10, what lb_gemm_plan now takes) accumulates every output in the
+    same K order as the 6-wave form of rounds 2-5 (tile code 7): identical bits, with bias + residual and as a GEGLU."""
+    o, l = ops(), lib()
+    M, N, K = shape
+    A, W = rnd(M, K, seed=311).to(DEV), rnd(N, K, seed=312, scale=K ** -0.5).to(DEV)
+    bias, res = rnd(N, seed=313, dtype=torch.float32).to(DEV), rnd(M, N, seed=314).to(DEV)
+    outs = {}
+    try:
+        for tile in (7, 10):
+            l.api.lb_gemm_set_tuning(tile, 1)
+            outs[tile] = (o.gemm(A, W, bias=bias, residual=res), o.gemm(A, W[: N // 8 * 8], bias=bias[: N // 8 * 8], flags=l.GEMM_GEGLU))
+    finally:
+        l.api.lb_gemm_set_tuning(0, 0)
+    assert torch.equal(outs[7][0], outs[10][0]) and torch.equal(outs[7][1], outs[10][1])
+
+
 # ------------------------------------------------------------------ one-round-trip tile epilogue (lb_gemm.h, round 5)
 def _lean_ab(fn):
     """fn() with the per-row epilogue everywhere, then with the one-round-trip form: both results."""
@@ -899,7 +930,7 @@ def _lean_ab(fn):
     return a, fn()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 7, 9, 10])
 @pytest.mark.parametrize("shape", [(4352, 1280, 640), (1000, 384, 256), (300, 260, 128), (512, 768, 192)])
 def test_lean_epilogue_gemm_bit_identical(shape, tile, results_log):
     """Every tile family, whole and ragged wave tiles (M = 1000 / 300: masked rows; N = 260 / 384: wave tiles that overhang N fall back
