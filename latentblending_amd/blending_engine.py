@@ -881,8 +881,11 @@ class BlendingEngine:
     def _skip_noise_draws(self, n):
         sched = getattr(self.dh.pipe, "scheduler", None)
         src = getattr(sched, "noise_source", None)
-        if src is not None and getattr(sched, "ancestral", False):
+        if src is not None and getattr(sched, "ancestral", False) and n > 0:
             shape = (1, self.dh.pipe.unet.config.in_channels, self.dh.height_latent, self.dh.width_latent)
+            if hasattr(src, "many"):        # the ranks that DO draw make one generator call for these n latents (native pipe,
+                src.many(n, shape)          # scheduler.draw_noise_many): the same call keeps a shared device stream aligned
+                return
             for _ in range(n):
                 src(shape)
 

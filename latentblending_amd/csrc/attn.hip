@@ -312,6 +312,273 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: the streaming form (64-key tiles, 3-stage ring) with the VALU work per tile halved.  PMC of the kernel above on the UNet's
+// self-attention (profiles/r04_attention_pmc.json): 233 VALU instructions per (wave, tile) = 1,063 issue cycles (a wave64 VALU
+// instruction occupies its SIMD for 4 cycles, v_exp_f32 for 8) against 576 cycles of MFMA - with three waves per SIMD the VALU
+// pipe is 75 % busy and the matrix pipe 40 %: the kernel is VALU-bound, not matrix-bound.  What went:
+//   * the 32 v_fma (score * scale * log2e - max) per tile: Q is multiplied by scale * log2e ONCE in the prologue (one extra fp16
+//     rounding of Q, of the size of the rounding the projection already applied), and -max enters as the ACCUMULATOR INPUT of the
+//     first QK^T MFMA, so the matrix pipe returns (score - max) in the exp2 domain and the probabilities are v_exp_f32 of the
+//     accumulators as they are;
+//   * the two ds_bpermute round trips of every row-max: v_permlane16_swap / v_permlane32_swap (VALU, no LDS crossbar);
+//   * ~50 instructions of per-tile bookkeeping: 64-bit address arithmetic behind exec-masked branches for every direct-to-LDS
+//     request (now a uniform base + a 32-bit running offset clamped to the last row - rows past the sequence re-read the last row,
+//     their probabilities are exactly 0), the key indices of the mask (now inside the ragged branch only);
+//   * the K fragments of a tile are read into registers up front (the budget of three waves per SIMD is 168 VGPRs; the old kernel
+//     used 133 and exposed one LDS latency per 16-key block).
+// The running maximum is kept in the same deferred form (it moves when a score outgrows it by 2^ATT_DEFER); a move re-bases the
+// scores already computed against the old maximum inside the (rare) branch.
+// ------------------------------------------------------------------------------------------
+template <int QG>
+__global__ void __launch_bounds__(256) attn_fwd_d64_stream_kernel(const LbAttnParams p) {
+    constexpr int KT = 64, NS = 3, NKB = KT / 16, NKS = KT / 32, NL = 4;
+    constexpr int STAGE = 2 * KT * ATT_D;   // halves per ring stage: K tile, then V tile
+    extern __shared__ __attribute__((aligned(16))) f16 att_lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (64 * QG) + wave * (16 * QG));      // (wave-uniform: keep it scalar)
+    const f16* Q = reinterpret_cast<const f16*>(p.Q);
+    f16* O = reinterpret_cast<f16*>(p.O);
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lane_k = 4 * g, lane_c = 4 * g - l16;     // masks compare these lane constants with per-(tile, block, r) scalars
+
+    // ---- loader: thread (r0 = tid>>3 (+32), c = tid&7) owns physical chunk c of tile rows r0, r0 + 32 and fetches logical chunk
+    //      c ^ (row & 7).  Uniform base pointer + 32-bit element offset, advanced by one tile per request and clamped to the last row.
+    const int r0 = tid >> 3;
+    const int cl = (tid & 7) ^ (r0 & 7);
+    const f16* kbase = reinterpret_cast<const f16*>(p.K) + (long)b * p.Skv * p.ldk + h * ATT_D;
+    const f16* vbase = reinterpret_cast<const f16*>(p.V) + (long)b * p.Skv * p.ldv + h * ATT_D;
+    const unsigned kmax = (unsigned)(p.Skv - 1) * p.ldk + cl * 8, vmax = (unsigned)(p.Skv - 1) * p.ldv + cl * 8;
+    unsigned ko[2], vo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ko[i] = min((unsigned)(r0 + 32 * i) * p.ldk + cl * 8, kmax);
+        vo[i] = min((unsigned)(r0 + 32 * i) * p.ldv + cl * 8, vmax);
+    }
+    const unsigned kstep = (unsigned)KT * p.ldk, vstep = (unsigned)KT * p.ldv;
+    auto issue_tile = [&](int st) {
+        f16* base = att_lds + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(kbase + ko[i]), (att_lptr_t)(base + (wave * 8 + i * 32) * ATT_D), 16, 0, 0);
+            ko[i] = min(ko[i] + kstep, kmax);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((att_gptr_t)(vbase + vo[i]), (att_lptr_t)(base + KT * ATT_D + (wave * 8 + i * 32) * ATT_D), 16, 0, 0);
+            vo[i] = min(vo[i] + vstep, vmax);
+        }
+    };
+
+    const int nt = (p.Skv + KT - 1) / KT;
+    // ---- prologue: Q fragments (b operand: k = d = 32 s + 8 g .. +8) first, then tiles 0 .. NS-2 in flight; Q is carried into the
+    //      exp2 domain here: q * (scale * log2 e), rounded to fp16 once ----
+    const float sc = p.scale * 1.44269504088896340736f;
+    f16x8 qraw[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const int q_row = q0 + qg * 16 + l16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qraw[qg][s] = zero8;
+            if (q_row < p.Sq)
+                qraw[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_tile(s);
+    f16x8 qf[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[qg][s][e] = (f16)((float)qraw[qg][s][e] * sc);
+
+    // ---- loop-invariant LDS offsets (halves, relative to the stage base): as in attn_fwd_d64_kernel ----
+    int koff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) koff[s] = l16 * ATT_D + (((s * 4 + g) ^ (l16 & 7)) << 3);
+    const int vrow = 4 * g + (l16 >> 2);
+    const int vsw = vrow & 7;
+    int voff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        voff[dt] = KT * ATT_D + vrow * ATT_D + (((2 * dt + ((l16 & 3) >> 1)) ^ vsw) << 3) + (l16 & 1) * 4;
+
+    f32x4 ot[QG][4], lt[QG], negm[QG];      // negm: -running maximum (exp2 domain), the accumulator input of QK^T
+    float m_use[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m_use[qg] = 0.f;
+        negm[qg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lt[qg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[qg][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+
+    int st = 0;
+    for (int t = 0; t < nt; ++t) {
+        att_wait_vm_barrier<(NS - 2) * NL>();     // tile t landed everywhere; stage (t-1) % NS is free everywhere
+        {
+            int refill = st - 1;
+            if (refill < 0) refill += NS;
+            issue_tile(refill);                   // (clamped to the last row past the end: the counts stay constant)
+        }
+        const f16* Ks = att_lds + st * STAGE;
+
+        // ---- S^T - max = K . Q^T + (-max): every K fragment of the tile is requested before the first MFMA ----
+        f16x8 kf[NKB][2];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kf[kb][s] = *reinterpret_cast<const f16x8*>(Ks + kb * 16 * ATT_D + koff[s]);
+        f32x4 sacc[QG][NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qg][0], negm[qg], 0, 0, 0);
+                sacc[qg][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qg][1], a, 0, 0, 0);
+            }
+        // ---- online softmax (this lane: one query per group, keys 16 kb + 4 g + r of the tile) ----
+        const bool ragged = (t + 1) * KT > p.Skv_valid || (p.causal && (t + 1) * KT > q0);      // wave-uniform
+        f16x8 pf[QG][NKS];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            if (ragged) {       // key = t KT + 16 kb + 4 g + r is masked when key >= Skv_valid, or (causal) key > q0 + 16 qg + l16
+                const int vrel = p.Skv_valid - t * KT, crel = q0 + qg * 16 - t * KT;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (lane_k >= vrel - kb * 16 - r || (p.causal && lane_c > crel - kb * 16 - r)) sacc[qg][kb][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(fmaxf(sacc[qg][0][0], sacc[qg][0][1]), sacc[qg][0][2]), sacc[qg][0][3]);
+#pragma unroll
+            for (int kb = 1; kb < NKB; ++kb)      // (a chain: two v_max3 per key block)
+                mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, sacc[qg][kb][0]), sacc[qg][kb][1]), sacc[qg][kb][2]), sacc[qg][kb][3]);
+            {   // the query's other three 16-lane rows: permlane swaps instead of ds_bpermute round trips
+                const unsigned u = __float_as_uint(mx);
+                const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                const unsigned v = __float_as_uint(fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1])));
+                const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+            }
+            // mx is RELATIVE to the running maximum.  Deferred rescale: the maximum moves (and O, l are rescaled, and the scores
+            // of this tile re-based) only when some query of the wave outgrew it by more than 2^ATT_DEFER; the first tile sets it
+            // (every query sees at least key 0 there: Skv_valid > 0, causal k <= q).
+            if (t == 0 || __any(mx > ATT_DEFER)) {
+                const float m_abs = mx + m_use[qg];
+                const float m_new = t == 0 ? m_abs : fmaxf(m_use[qg], m_abs);
+                const float delta = m_new - m_use[qg];
+                const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                m_use[qg] = m_new;
+                negm[qg] = (f32x4){-m_new, -m_new, -m_new, -m_new};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[qg][kb][r] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[qg][dt][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lt[qg][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pf[qg][kb >> 1][(kb & 1) * 4 + r] = (f16)__builtin_amdgcn_exp2f(sacc[qg][kb][r]);
+        }
+        // ---- O^T += V^T . P^T ----  (V^T fragments of both k-steps are requested before the first MFMA)
+        {
+            const unsigned vb = att_lds_addr(Ks);
+            f16x4 vlo[NKS][4], vhi[NKS][4];
+            auto request = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    vlo[ks][dt] = att_tr_read<(32 * ks) * ATT_D * 2>(vb + voff[dt] * 2);
+                    vhi[ks][dt] = att_tr_read<(32 * ks + 16) * ATT_D * 2>(vb + voff[dt] * 2);
+                }
+            };
+            auto multiply = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f16x8 vf = {vlo[ks][dt][0], vlo[ks][dt][1], vlo[ks][dt][2], vlo[ks][dt][3],
+                                      vhi[ks][dt][0], vhi[ks][dt][1], vhi[ks][dt][2], vhi[ks][dt][3]};
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+                        ot[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qg][ks], ot[qg][dt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    lt[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[qg][ks], lt[qg], 0, 0, 0);
+            };
+            request(AttInt<0>{});
+            request(AttInt<1>{});
+            att_tr_wait<8>();
+            multiply(AttInt<0>{});
+            att_tr_wait<0>();
+            multiply(AttInt<1>{});
+        }
+        st = st + 1 == NS ? 0 : st + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the tail requests before the block may exit
+
+    // Output: as attn_fwd_d64_kernel (lane (g, l16) holds O[q = l16][d = 16 dt + 4 g + r]; paired 16-byte stores in the wide form)
+    const bool wide = (p.reserved_ & 1) != 0;
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const float l = lt[qg][0];
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const int q_row = q0 + qg * 16 + l16;
+        f16* orow = O + ((long)b * p.Sq + (q_row < p.Sq ? q_row : p.Sq - 1)) * p.ldo + h * ATT_D;
+        if (wide) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                unsigned u[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f32x4 a = ot[qg][2 * pr + k];
+                    u[k][0] = __builtin_bit_cast(unsigned, (att_h2){(f16)(a[0] * inv), (f16)(a[1] * inv)});
+                    u[k][1] = __builtin_bit_cast(unsigned, (att_h2){(f16)(a[2] * inv), (f16)(a[3] * inv)});
+                }
+                const auto r0_ = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
+                const auto r1_ = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
+                const int n = (2 * pr + 1) * 16 + 4 * g;
+                const int nst = (g & 1) ? n - 4 : n - 16;
+                typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+                if (q_row < p.Sq) *reinterpret_cast<att_u4*>(orow + nst) = (att_u4){r0_[0], r1_[0], r0_[1], r1_[1]};
+            }
+            continue;
+        }
+        if (q_row < p.Sq) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f16x4 o = {(f16)(ot[qg][dt][0] * inv), (f16)(ot[qg][dt][1] * inv), (f16)(ot[qg][dt][2] * inv),
+                                 (f16)(ot[qg][dt][3] * inv)};
+                *reinterpret_cast<f16x4*>(orow + dt * 16 + 4 * g) = o;
+            }
+        }
+    }
+}
+
+template <int QG>
+static void attn_launch_stream(const LbAttnParams& p, hipStream_t s) {
+    const size_t smem = (size_t)3 * 2 * 64 * ATT_D * sizeof(f16);
+    const dim3 grid((p.Sq + 64 * QG - 1) / (64 * QG), p.H, p.B);
+    hipLaunchKernelGGL((attn_fwd_d64_stream_kernel<QG>), grid, dim3(256), smem, s, p);
+}
+
 template <int KT, int QG, int NS>
 static void attn_launch(const LbAttnParams& p, hipStream_t s) {
     const size_t smem = (size_t)NS * 2 * KT * ATT_D * sizeof(f16);
@@ -325,7 +592,8 @@ static void attn_launch(const LbAttnParams& p, hipStream_t s) {
 }
 
 // variant (testing): 0 = by shape, else bit 0..1 QG (1 / 2), bit 4 forces the 64-key streaming tile, bit 5 = a 5-stage ring for the
-// streaming form (80 KiB: a sequence of <= 256 keys is then requested whole in the prologue; A/B knob, not a default)
+// streaming form (80 KiB: a sequence of <= 256 keys is then requested whole in the prologue; A/B knob, not a default), bit 8 = the
+// streaming kernel of rounds 1-5 (attn_fwd_d64_kernel<64, QG, 3>) instead of attn_fwd_d64_stream_kernel
 static int g_attn_force = 0;
 extern "C" void lb_attn_set_tuning(int force) { g_attn_force = force; }
 
@@ -345,7 +613,8 @@ static int attn_dispatch(const LbAttnParams& pin, int force, hipStream_t s) {
     if (single && !(force & 64)) { if (qg == 2) attn_launch<96, 2, 1>(p, s); else attn_launch<96, 1, 1>(p, s); }
     else if (single) { if (qg == 2) attn_launch<96, 2, 2>(p, s); else attn_launch<96, 1, 2>(p, s); }
     else if (force & 32) { if (qg == 2) attn_launch<64, 2, 5>(p, s); else attn_launch<64, 1, 5>(p, s); }
-    else        { if (qg == 2) attn_launch<64, 2, 3>(p, s); else attn_launch<64, 1, 3>(p, s); }
+    else if (force & 256) { if (qg == 2) attn_launch<64, 2, 3>(p, s); else attn_launch<64, 1, 3>(p, s); }      // (rounds 1-5 streaming kernel: A/B)
+    else        { if (qg == 2) attn_launch_stream<2>(p, s); else attn_launch_stream<1>(p, s); }
     return lb_check_launch("lb_attn_fwd_d64");
 }
 

@@ -358,9 +358,9 @@ class StableDiffusionXLPipeline:
         if sched.ancestral and num_inference_steps > idx_start:
             shape1 = (1,) + tuple(latents.shape[1:])
             n_draw, keep = (G, list(range(G))) if noise_slots is None else (int(noise_slots[0]), list(noise_slots[1]))
-            per_branch = [torch.cat([sched.draw_noise(shape1, self.device)
-                                     for _ in range(idx_start, num_inference_steps)]) for _ in range(n_draw)]
-            noise_all = torch.stack([per_branch[k] for k in keep], dim=1).contiguous()       # [steps, G, 4, L, L]
+            nm = num_inference_steps - idx_start
+            drawn = sched.draw_noise_many(n_draw * nm, shape1, self.device).view(n_draw, nm, *shape1[1:])
+            noise_all = drawn[keep].transpose(0, 1).contiguous()                             # [steps, G, 4, L, L]
         for i in range(idx_start, num_inference_steps):
             if i > 0:
                 mix = [g for g in range(G) if coeffs_list[g][i] > 0]
@@ -480,12 +480,11 @@ class StableDiffusionXLPipeline:
         shape1 = (1,) + tuple(ref_start.shape[1:])
         noise_a = noise_m = None
         if sched.ancestral:       # sample-major draws: anchor 1, anchor 2 (those denoised here), then every mid branch
-            noise_a = torch.stack([torch.cat([sched.draw_noise(shape1, self.device) for _ in range(steps)])
-                                   for _ in range(A)], dim=1) if A else None
             n_draw, keep = (G, list(range(G))) if noise_slots is None else (int(noise_slots[0]), list(noise_slots[1]))
-            drawn = [torch.cat([sched.draw_noise(shape1, self.device) for _ in range(idx_injection, steps)])
-                     for _ in range(n_draw)]
-            noise_m = torch.stack([drawn[k] for k in keep], dim=1) if G else None
+            nm = steps - idx_injection
+            flat = sched.draw_noise_many(A * steps + n_draw * nm, shape1, self.device)      # ONE launch on the device RNG
+            noise_a = flat[:A * steps].view(A, steps, *shape1[1:]).transpose(0, 1) if A else None          # [steps, A, 4, L, L]
+            noise_m = flat[A * steps:].view(n_draw, nm, *shape1[1:])[keep].transpose(0, 1) if G else None   # [nm, G, 4, L, L]
         lat_shape = (int(ref_start.shape[-3]), L, L)
         lat_a = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in anchor_starts]).contiguous() if A else \
             torch.empty((0,) + lat_shape, dtype=F16, device=self.device)

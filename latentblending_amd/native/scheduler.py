@@ -37,6 +37,11 @@ class SeededDeviceNoise:
     def __call__(self, shape):
         return torch.randn(tuple(shape), generator=self.gen, device=self.device, dtype=torch.float16)
 
+    def many(self, n: int, shape):
+        """``n`` draws of ``shape`` ([1, ...]) stacked along dim 0 as ONE generator call (one launch instead of n; every rank of a
+        farm makes the same call, so the streams stay aligned)."""
+        return torch.randn((int(n),) + tuple(shape[1:]), generator=self.gen, device=self.device, dtype=torch.float16)
+
 
 class NativeEulerScheduler:
     order = 1
@@ -103,6 +108,20 @@ class NativeEulerScheduler:
         if self.noise_source is not None:
             return self.noise_source(tuple(shape)).to(device=device, dtype=torch.float16)
         return torch.randn(shape, device=device, dtype=torch.float16)
+
+    def draw_noise_many(self, n: int, shape, device) -> torch.Tensor:
+        """``n`` draws of ``shape`` ([1, C, L, L]) stacked along dim 0, in draw order.  The device RNG (and a noise source with a
+        ``many`` method) serves them with ONE launch - a cfg-2 transition draws 38 latents' worth of ancestral noise, 38 launches of
+        ~14 us each before round 6; a source without ``many`` (a recorded tape) is called once per draw, in the same order."""
+        n = int(n)
+        if n == 0:
+            return torch.empty((0,) + tuple(shape[1:]), device=device, dtype=torch.float16)
+        if self.noise_source is None:
+            return torch.randn((n,) + tuple(shape[1:]), device=device, dtype=torch.float16)
+        many = getattr(self.noise_source, "many", None)
+        if many is not None:
+            return many(n, tuple(shape)).to(device=device, dtype=torch.float16)
+        return torch.cat([self.draw_noise(shape, device) for _ in range(n)])
 
     def step(self, model_output, timestep, sample, generator=None, return_dict=False, **_):
         i = self._locate(timestep)

@@ -496,8 +496,9 @@ def test_attention_d64(case, results_log):
 
 
 # (49 / 50 = bit 5: the 5-stage-ring A/B form added at the end of round 3 without a GPU run: opt in with LB_TEST_EXPERIMENTAL=1)
-# (bit 6 = the former two-stage form of the one-tile kernel, bit 7 = 8-byte output stores instead of the paired 16-byte ones)
-@pytest.mark.parametrize("force", [1, 2, 17, 18, 65, 66, 129, 130] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
+# (bit 6 = the former two-stage form of the one-tile kernel, bit 7 = 8-byte output stores instead of the paired 16-byte ones,
+#  bit 8 = the streaming kernel of rounds 1-5; without it streamed shapes run attn_fwd_d64_stream_kernel, round 6)
+@pytest.mark.parametrize("force", [1, 2, 17, 18, 65, 66, 129, 130, 257, 258, 273] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
 @pytest.mark.parametrize("case", [(2, 3, 300, 300, 300), (2, 2, 130, 80, 77), (1, 2, 70, 96, 90), (1, 1, 16, 8, 5)])
 def test_attention_d64_variants(case, force, results_log):
     """Every kernel variant (1 / 2 query groups per wave, single 96-key tile / streamed 64-key tiles) on ragged shapes,
@@ -566,6 +567,8 @@ def test_attention_spiked_scores(results_log):
     q, k, v = rnd(B, S, C, seed=54), rnd(B, S, C, seed=55), rnd(B, S, C, seed=56)
     k[0, 200] = q[0, 3] * 6.0          # one key far above the rest, in the last tile
     k[0, 70] = q[0, 100] * 4.0
+    k[0, :64] = -q[0, 5:6] * 5.0       # query 5: every score of the FIRST tile far below zero (the first tile sets the running maximum
+    #                                    whatever its sign; the later tiles then raise it by ~2^60)
     ref = R.attention(q.float(), k.float(), v.float(), H)
     got = o.attention_d64(q.reshape(S, C).to(DEV), k.reshape(S, C).to(DEV), v.reshape(S, C).to(DEV), B, H, S, S)
     check_close(results_log, "attn_spiked", got.reshape(B, S, C), ref, floor=2e-3)

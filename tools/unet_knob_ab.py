@@ -14,18 +14,21 @@ import latentblending_amd.native as N
 from latentblending_amd.hip import lib
 
 DEV = "cuda:0"
+# round 6: the knobs are this round's kernel changes, each switched back to its round-5 form (rounds 3-4 swept ring depths and the
+# ping-pong policy: profiles/r04_unet_knob_ab.txt)
 KNOBS = [("default", lambda: None),
-         ("gemm ring 2", lambda: lib.api.lb_gemm_set_variant(1, 2)),
-         ("gemm ring 3", lambda: lib.api.lb_gemm_set_variant(1, 3)),
-         ("gemm ring 4", lambda: lib.api.lb_gemm_set_variant(1, 4)),
-         ("attention 5-stage ring", lambda: lib.api.lb_attn_set_tuning(32)),
-         ("ping-pong GEMM off", lambda: lib.api.lb_gemm_set_pp_auto(0))]
+         ("attention: r1-5 streaming kernel", lambda: lib.api.lb_attn_set_tuning(256)),
+         ("layernorm: r1 kernel", lambda: lib.api.lb_layernorm_set_form(0)),
+         ("192x128 tile: 6 waves", lambda: lib.api.lb_gemm_set_t192_waves8(0)),
+         ("all three as in round 5", lambda: (lib.api.lb_attn_set_tuning(256), lib.api.lb_layernorm_set_form(0), lib.api.lb_gemm_set_t192_waves8(0)))]
 
 
 def reset():
     lib.api.lb_gemm_set_variant(-1, 0)
     lib.api.lb_attn_set_tuning(0)
     lib.api.lb_gemm_set_pp_auto(1)
+    lib.api.lb_layernorm_set_form(1)
+    lib.api.lb_gemm_set_t192_waves8(1)
 
 
 def timed(launch, iters):
