@@ -163,6 +163,7 @@ int lb_upconv2x_halo_f16(const LbGemmParams* params, void* stream);
 void lb_gemm_set_halo(int mode);
 void lb_gemm_set_wide_store(int on);              /* tuning: 1 = 16-byte epilogue stores for fp16 row-major outputs (same results) */
 void lb_gemm_set_t192_waves8(int on);             /* tuning: 1 (default) = the 192x128 tile runs 8 waves of 48x64 (tile code 10), 0 = 6 waves of 64x64 (tile code 7); same results */
+void lb_gemm_set_kgroups(int on);                 /* tuning: 1 (default) = 64x64 grids of <= 200 unsplit blocks run two K-groups of 4 waves per block (tile code 11: partial sums added through LDS), 0 = never */
 void lb_gemm_set_lean_epilogue(int on);           /* tuning: 1 (default) = one-round-trip tile epilogue where it applies, 0 = the per-row form everywhere (same results) */
 void lb_gemm_set_variant(int variant, int stages); /* 0 = register ring, 1 = direct-to-LDS (stages 2..4, 0 = default), <0 = library default */
 
@@ -182,6 +183,7 @@ long lb_groupnorm_workspace_bytes(int B, int groups);
 int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace,
                       int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,
                       int x_is_f32, void* stream);
+void lb_groupnorm_set_fused(int on);    /* testing: 1 (default) = lb_groupnorm_nhwc runs as ONE launch (slab in registers) wherever a (sample, lcm(8, C / groups)-channel slab) fits a block: <= 24 pixels per thread; 0 = always statistics + apply launches */
 int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int M, int C,
                      int ldx, int ldy, float eps, void* stream);
 void lb_layernorm_set_form(int form);   /* testing: 1 (default) = all loads of a row in flight + permlane / DPP reductions (round 6), 0 = the round-1 kernel; bit-identical results */

@@ -65,6 +65,39 @@ __device__ __forceinline__ unsigned att_lds_addr(const void* p) { return (unsign
 
 typedef _Float16 att_h2 __attribute__((ext_vector_type(2)));
 
+// Block -> (query block, head, sample).  The hardware places consecutive workgroup ids on consecutive XCDs (id % 8), each with its own
+// L2: under the 3-D grid of rounds 1-5 (query block fastest) the blocks that stream the SAME K / V of one (sample, head) sat on
+// different XCDs, and every XCD fetched that K / V through the fabric for itself - 8 x the bytes at S = 1024 (348 MB per launch at
+// B = 17: ~4.5 TB/s of fabric traffic, which is what bounded every form of the kernel at ~80 us).  1-D grid: XCD k serves the (sample,
+// head) pairs 8 g + k, all query blocks of a pair back to back on that XCD; a tail of < 8 pairs is laid out linearly.  Bijective.
+// p.reserved_ bit 1 = the old order (A/B).
+struct AttBlock { int qb, h, b; };
+__device__ __forceinline__ AttBlock att_block(const LbAttnParams& p, int rows_per_block) {
+    const int nqb = (p.Sq + rows_per_block - 1) / rows_per_block;
+    const int id = blockIdx.x;
+    int qb, pair;
+    if (p.reserved_ & 2) {
+        qb = id % nqb;
+        pair = id / nqb;
+    } else {
+        const int n_pairs = p.H * p.B, full = (n_pairs >> 3) * 8 * nqb;      // blocks of the complete groups of 8 pairs
+        if (id < full) {
+            const int xcd = id & 7, slot = id >> 3;
+            qb = slot % nqb;
+            pair = (slot / nqb) * 8 + xcd;
+        } else {
+            const int tail = id - full;
+            qb = tail % nqb;
+            pair = (n_pairs >> 3) * 8 + tail / nqb;
+        }
+    }
+    AttBlock r;
+    r.qb = qb;
+    r.h = pair % p.H;
+    r.b = pair / p.H;
+    return r;
+}
+
 template <int KT, int QG, int NS>
 __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p) {
     constexpr int NKB = KT / 16;            // 16-key blocks of S^T per tile
@@ -76,8 +109,9 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (64 * QG) + wave * (16 * QG);
+    const AttBlock blk = att_block(p, 64 * QG);
+    const int b = blk.b, h = blk.h;
+    const int q0 = blk.qb * (64 * QG) + wave * (16 * QG);
     const f16* Q = reinterpret_cast<const f16*>(p.Q);
     const f16* K = reinterpret_cast<const f16*>(p.K);
     const f16* V = reinterpret_cast<const f16*>(p.V);
@@ -111,16 +145,15 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_kernel(const LbAttnParams p)
     // ---- prologue: the Q fragments (b operand: k = d = 32 s + 8 g .. +8) are requested FIRST (requests retire in
     //      order: the counted waits of the loop then never wait for a younger request than they mean), then tiles
     //      0 .. NS-2 go in flight ----
+    // (rows past Sq re-read the last row - their results are never stored: no exec-masked block per load, behind each of which
+    //  hipcc waits for vmcnt(0), i.e. four serialised memory round trips in front of the first tile request until round 5)
     f16x8 qf[QG][2];
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        const int q_row = q0 + qg * 16 + l16;
+        const int q_row = min(q0 + qg * 16 + l16, p.Sq - 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qf[qg][s] = zero8;
-            if (q_row < p.Sq)
-                qf[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
-        }
+        for (int s = 0; s < 2; ++s)
+            qf[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -338,8 +371,9 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_stream_kernel(const LbAttnPa
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l16 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (64 * QG) + wave * (16 * QG));      // (wave-uniform: keep it scalar)
+    const AttBlock blk = att_block(p, 64 * QG);
+    const int b = blk.b, h = blk.h;
+    const int q0 = __builtin_amdgcn_readfirstlane(blk.qb * (64 * QG) + wave * (16 * QG));      // (wave-uniform: keep it scalar)
     const f16* Q = reinterpret_cast<const f16*>(p.Q);
     f16* O = reinterpret_cast<f16*>(p.O);
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -377,16 +411,13 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_stream_kernel(const LbAttnPa
     // ---- prologue: Q fragments (b operand: k = d = 32 s + 8 g .. +8) first, then tiles 0 .. NS-2 in flight; Q is carried into the
     //      exp2 domain here: q * (scale * log2 e), rounded to fp16 once ----
     const float sc = p.scale * 1.44269504088896340736f;
-    f16x8 qraw[QG][2];
+    f16x8 qraw[QG][2];      // (rows past Sq re-read the last row - never stored: no exec-masked load blocks, see attn_fwd_d64_kernel)
 #pragma unroll
     for (int qg = 0; qg < QG; ++qg) {
-        const int q_row = q0 + qg * 16 + l16;
+        const int q_row = min(q0 + qg * 16 + l16, p.Sq - 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qraw[qg][s] = zero8;
-            if (q_row < p.Sq)
-                qraw[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
-        }
+        for (int s = 0; s < 2; ++s)
+            qraw[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -572,10 +603,274 @@ __global__ void __launch_bounds__(256) attn_fwd_d64_stream_kernel(const LbAttnPa
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: PING-PONG form of the streaming kernel.  The three co-resident blocks of attn_fwd_d64_stream_kernel run the same
+// instruction stream from the same start: their waves meet in the same phase on a SIMD - all of them multiplying (matrix pipe
+// contended, VALU idle), then all of them exponentiating (VALU contended, matrix pipe idle) - and a tile costs a SIMD the SUM of
+// both phases (measured: 1,890 cycles per (wave, tile) for 576 of MFMA + ~650 of VALU).  Here a block has 8 waves = two groups
+// of four; waves w and w + 4 share a SIMD, and group B runs exactly one phase behind group A, one s_barrier per phase:
+//        phase      0       1        2         3         4
+//        group A   QK(0)   SM(0)   PV(0)+QK(1) SM(1)   PV(1)+QK(2) ...          SM = softmax (VALU), PV / QK = MFMA
+//        group B    -      QK(0)   SM(0)     PV(0)+QK(1) SM(1)     ...
+// so that a SIMD always holds one wave in its matrix phase and one in its VALU phase.  Both groups stream the SAME 64-key tiles
+// (the block owns 128 QG consecutive queries of one head): every thread requests one 16-byte chunk of K and one of V per tile
+// (512 threads = 64 rows x 8 chunks), in the even phases; a 4-stage ring: stage t % 4 is read in phases 2t .. 2t + 3 (K_t by QK(t)
+// of both groups, V_t by PV(t) of both groups), refilled with tile t + 3's successor in phase 2t + 2 ... i.e. tile t + 3 is
+// requested in phase 2t + 2 into the stage tile t - 1 left in phase 2t + 1, and must have landed by phase 2t + 6: every wave waits
+// vmcnt(2) (one younger tile may still be in flight) at the end of the odd phases.  The arithmetic per wave is that of
+// attn_fwd_d64_stream_kernel (same instruction order inside QK / SM / PV): bit-identical outputs.
+// ------------------------------------------------------------------------------------------
+template <int QG>
+__global__ void __launch_bounds__(512, QG == 1 ? 4 : 2) attn_fwd_d64_pp_kernel(const LbAttnParams p) {
+    constexpr int KT = 64, NS = 4, NKB = KT / 16, NKS = KT / 32;
+    constexpr int STAGE = 2 * KT * ATT_D;   // halves per ring stage: K tile, then V tile
+    extern __shared__ __attribute__((aligned(16))) f16 att_lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const AttBlock blk = att_block(p, 128 * QG);
+    const int b = blk.b, h = blk.h;
+    const bool grpB = __builtin_amdgcn_readfirstlane(wave >> 2) != 0;
+    const int q0 = __builtin_amdgcn_readfirstlane(blk.qb * (128 * QG) + wave * (16 * QG));
+    const f16* Q = reinterpret_cast<const f16*>(p.Q);
+    f16* O = reinterpret_cast<f16*>(p.O);
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int lane_k = 4 * g, lane_c = 4 * g - l16;
+
+    // ---- loader: thread (row = tid>>3, c = tid&7) owns physical chunk c of tile row `row` (K and V) and fetches logical chunk c ^ (row & 7)
+    const int r0 = tid >> 3;
+    const int cl = (tid & 7) ^ (r0 & 7);
+    const f16* kbase = reinterpret_cast<const f16*>(p.K) + (long)b * p.Skv * p.ldk + h * ATT_D;
+    const f16* vbase = reinterpret_cast<const f16*>(p.V) + (long)b * p.Skv * p.ldv + h * ATT_D;
+    const unsigned kmax = (unsigned)(p.Skv - 1) * p.ldk + cl * 8, vmax = (unsigned)(p.Skv - 1) * p.ldv + cl * 8;
+    unsigned ko = min((unsigned)r0 * p.ldk + cl * 8, kmax), vo = min((unsigned)r0 * p.ldv + cl * 8, vmax);
+    const unsigned kstep = (unsigned)KT * p.ldk, vstep = (unsigned)KT * p.ldv;
+    auto issue_tile = [&](int st) {
+        f16* base = att_lds + st * STAGE;
+        __builtin_amdgcn_global_load_lds((att_gptr_t)(kbase + ko), (att_lptr_t)(base + (wave * 8) * ATT_D), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((att_gptr_t)(vbase + vo), (att_lptr_t)(base + KT * ATT_D + (wave * 8) * ATT_D), 16, 0, 0);
+        ko = min(ko + kstep, kmax);
+        vo = min(vo + vstep, vmax);
+    };
+
+    const int nt = (p.Skv + KT - 1) / KT;
+    const float sc = p.scale * 1.44269504088896340736f;
+    f16x8 qraw[QG][2];      // (rows past Sq re-read the last row - never stored: no exec-masked load blocks, see attn_fwd_d64_kernel)
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const int q_row = min(q0 + qg * 16 + l16, p.Sq - 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            qraw[qg][s] = *reinterpret_cast<const f16x8*>(Q + ((long)b * p.Sq + q_row) * p.ldq + h * ATT_D + s * 32 + g * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    issue_tile(0);      // (tiles 1 and 2 follow behind the first K-fragment reads: hipcc drains every direct-to-LDS request still in
+    //                     flight in front of the first ds_read of the straight-line code that issued it)
+    f16x8 qf[QG][2];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[qg][s][e] = (f16)((float)qraw[qg][s][e] * sc);
+
+    int koff[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) koff[s] = l16 * ATT_D + (((s * 4 + g) ^ (l16 & 7)) << 3);
+    const int vrow = 4 * g + (l16 >> 2);
+    const int vsw = vrow & 7;
+    int voff[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        voff[dt] = KT * ATT_D + vrow * ATT_D + (((2 * dt + ((l16 & 3) >> 1)) ^ vsw) << 3) + (l16 & 1) * 4;
+
+    f32x4 ot[QG][4], lt[QG], negm[QG];
+    float m_use[QG];
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        m_use[qg] = 0.f;
+        negm[qg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lt[qg] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) ot[qg][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+
+    f32x4 sacc[QG][NKB];
+    f16x8 kf[NKB][2];
+    auto read_k = [&](int st) {         // every K fragment of a tile (conflict-free ds_read_b128 of the swizzled rows)
+        const f16* Ks = att_lds + st * STAGE;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) kf[kb][s] = *reinterpret_cast<const f16x8*>(Ks + kb * 16 * ATT_D + koff[s]);
+    };
+    auto qk = [&]() {                   // S^T - max = K . Q^T + (-max)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int qg = 0; qg < QG; ++qg) {
+                const f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qg][0], negm[qg], 0, 0, 0);
+                sacc[qg][kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qg][1], a, 0, 0, 0);
+            }
+    };
+
+    // ---- phase 0 (group A) / phase 1 (group B): QK(0) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile 0 (this thread's part)
+    if (grpB) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                         // ... everybody's part
+    read_k(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    issue_tile(1);
+    issue_tile(2);
+    qk();
+    if (grpB) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // (end of an odd phase: tile 1)
+
+    int st = 0;                         // ring stage of tile t
+    for (int t = 0; t < nt; ++t) {
+        // ================= SM(t): VALU phase =================
+        __builtin_amdgcn_s_barrier();
+        if (grpB) issue_tile((st + 3) & 3);               // (even phase: tile t + 3 into the stage tile t - 1 has left)
+        const bool ragged = (t + 1) * KT > p.Skv_valid || (p.causal && (t + 1) * KT > q0);      // wave-uniform
+        f16x8 pf[QG][NKS];
+#pragma unroll
+        for (int qg = 0; qg < QG; ++qg) {
+            if (ragged) {
+                const int vrel = p.Skv_valid - t * KT, crel = q0 + qg * 16 - t * KT;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (lane_k >= vrel - kb * 16 - r || (p.causal && lane_c > crel - kb * 16 - r)) sacc[qg][kb][r] = -INFINITY;
+            }
+            float mx = fmaxf(fmaxf(fmaxf(sacc[qg][0][0], sacc[qg][0][1]), sacc[qg][0][2]), sacc[qg][0][3]);
+#pragma unroll
+            for (int kb = 1; kb < NKB; ++kb)
+                mx = fmaxf(fmaxf(fmaxf(fmaxf(mx, sacc[qg][kb][0]), sacc[qg][kb][1]), sacc[qg][kb][2]), sacc[qg][kb][3]);
+            {
+                const unsigned u = __float_as_uint(mx);
+                const auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+                const unsigned v = __float_as_uint(fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1])));
+                const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+                mx = fmaxf(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+            }
+            if (t == 0 || __any(mx > ATT_DEFER)) {
+                const float m_abs = mx + m_use[qg];
+                const float m_new = t == 0 ? m_abs : fmaxf(m_use[qg], m_abs);
+                const float delta = m_new - m_use[qg];
+                const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                m_use[qg] = m_new;
+                negm[qg] = (f32x4){-m_new, -m_new, -m_new, -m_new};
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc[qg][kb][r] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ot[qg][dt][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lt[qg][r] *= alpha;
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pf[qg][kb >> 1][(kb & 1) * 4 + r] = (f16)__builtin_amdgcn_exp2f(sacc[qg][kb][r]);
+        }
+        if (!grpB) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // (end of an odd phase: tile t + 1)
+        // ================= PV(t) + QK(t + 1): matrix phase =================
+        __builtin_amdgcn_s_barrier();
+        if (!grpB) issue_tile((st + 3) & 3);              // (even phase)
+        read_k((st + 1) & 3);           // K_{t+1}, requested ahead of the V^T fragments (past the end: the clamped tile, scores unused)
+        {
+            const unsigned vb = att_lds_addr(att_lds + st * STAGE);
+            f16x4 vlo[NKS][4], vhi[NKS][4];
+            auto request = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    vlo[ks][dt] = att_tr_read<(32 * ks) * ATT_D * 2>(vb + voff[dt] * 2);
+                    vhi[ks][dt] = att_tr_read<(32 * ks + 16) * ATT_D * 2>(vb + voff[dt] * 2);
+                }
+            };
+            auto multiply = [&](auto ks_c) {
+                constexpr int ks = decltype(ks_c)::value;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f16x8 vf = {vlo[ks][dt][0], vlo[ks][dt][1], vlo[ks][dt][2], vlo[ks][dt][3],
+                                      vhi[ks][dt][0], vhi[ks][dt][1], vhi[ks][dt][2], vhi[ks][dt][3]};
+#pragma unroll
+                    for (int qg = 0; qg < QG; ++qg)
+                        ot[qg][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qg][ks], ot[qg][dt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int qg = 0; qg < QG; ++qg)
+                    lt[qg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8, pf[qg][ks], lt[qg], 0, 0, 0);
+            };
+            request(AttInt<0>{});
+            request(AttInt<1>{});
+            att_tr_wait<8>();           // (LDS returns in order: the 8 K fragments and the first 8 V^T reads have arrived)
+            multiply(AttInt<0>{});
+            att_tr_wait<0>();
+            multiply(AttInt<1>{});
+        }
+        st = (st + 1) & 3;
+        qk();
+        if (grpB) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // (end of an odd phase: tile t + 2)
+    }
+    if (!grpB) __builtin_amdgcn_s_barrier();              // (group B's last phase starts behind this barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the tail requests before the block may exit
+
+    const bool wide = (p.reserved_ & 1) != 0;
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+        const float l = lt[qg][0];
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const int q_row = q0 + qg * 16 + l16;
+        f16* orow = O + ((long)b * p.Sq + (q_row < p.Sq ? q_row : p.Sq - 1)) * p.ldo + h * ATT_D;
+        if (wide) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                unsigned u[2][2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const f32x4 a = ot[qg][2 * pr + k];
+                    u[k][0] = __builtin_bit_cast(unsigned, (att_h2){(f16)(a[0] * inv), (f16)(a[1] * inv)});
+                    u[k][1] = __builtin_bit_cast(unsigned, (att_h2){(f16)(a[2] * inv), (f16)(a[3] * inv)});
+                }
+                const auto r0_ = __builtin_amdgcn_permlane16_swap(u[0][0], u[1][0], false, false);
+                const auto r1_ = __builtin_amdgcn_permlane16_swap(u[0][1], u[1][1], false, false);
+                const int n = (2 * pr + 1) * 16 + 4 * g;
+                const int nst = (g & 1) ? n - 4 : n - 16;
+                typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+                if (q_row < p.Sq) *reinterpret_cast<att_u4*>(orow + nst) = (att_u4){r0_[0], r1_[0], r0_[1], r1_[1]};
+            }
+            continue;
+        }
+        if (q_row < p.Sq) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f16x4 o = {(f16)(ot[qg][dt][0] * inv), (f16)(ot[qg][dt][1] * inv), (f16)(ot[qg][dt][2] * inv),
+                                 (f16)(ot[qg][dt][3] * inv)};
+                *reinterpret_cast<f16x4*>(orow + dt * 16 + 4 * g) = o;
+            }
+        }
+    }
+}
+
+template <int QG>
+static void attn_launch_pp(const LbAttnParams& p, hipStream_t s) {
+    constexpr size_t smem = (size_t)4 * 2 * 64 * ATT_D * sizeof(f16);       // 64 KiB (QG = 1: 126 VGPRs, two blocks per CU; QG = 2: one)
+    const dim3 grid((unsigned)((p.Sq + 128 * QG - 1) / (128 * QG)) * p.H * p.B);
+    hipLaunchKernelGGL((attn_fwd_d64_pp_kernel<QG>), grid, dim3(512), smem, s, p);
+}
+
 template <int QG>
 static void attn_launch_stream(const LbAttnParams& p, hipStream_t s) {
     const size_t smem = (size_t)3 * 2 * 64 * ATT_D * sizeof(f16);
-    const dim3 grid((p.Sq + 64 * QG - 1) / (64 * QG), p.H, p.B);
+    const dim3 grid((unsigned)((p.Sq + 64 * QG - 1) / (64 * QG)) * p.H * p.B);
     hipLaunchKernelGGL((attn_fwd_d64_stream_kernel<QG>), grid, dim3(256), smem, s, p);
 }
 
@@ -587,19 +882,21 @@ static void attn_launch(const LbAttnParams& p, hipStream_t s) {
         if (lb_first_call_on_device(seen))
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_d64_kernel<KT, QG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
-    const dim3 grid((p.Sq + 64 * QG - 1) / (64 * QG), p.H, p.B);
+    const dim3 grid((unsigned)((p.Sq + 64 * QG - 1) / (64 * QG)) * p.H * p.B);
     hipLaunchKernelGGL((attn_fwd_d64_kernel<KT, QG, NS>), grid, dim3(256), smem, s, p);
 }
 
 // variant (testing): 0 = by shape, else bit 0..1 QG (1 / 2), bit 4 forces the 64-key streaming tile, bit 5 = a 5-stage ring for the
 // streaming form (80 KiB: a sequence of <= 256 keys is then requested whole in the prologue; A/B knob, not a default), bit 8 = the
-// streaming kernel of rounds 1-5 (attn_fwd_d64_kernel<64, QG, 3>) instead of attn_fwd_d64_stream_kernel
+// streaming kernel of rounds 1-5 (attn_fwd_d64_kernel<64, QG, 3>) instead of attn_fwd_d64_stream_kernel, bit 9 = the 8-wave ping-pong
+// form (attn_fwd_d64_pp_kernel), bit 11 = the block order of rounds 1-5 instead of the XCD-aware one
 static int g_attn_force = 0;
 extern "C" void lb_attn_set_tuning(int force) { g_attn_force = force; }
 
 static int attn_dispatch(const LbAttnParams& pin, int force, hipStream_t s) {
     LbAttnParams p = pin;
     p.reserved_ = (!(force & 128) && p.ldo % 8 == 0 && (reinterpret_cast<uintptr_t>(p.O) & 15) == 0) ? 1 : 0;    // 16-byte output stores
+    if (force & 2048) p.reserved_ |= 2;      // block order of rounds 1-5 (query block fastest: the sharers of a K / V on different XCDs)
     // short sequences (cross-attention: 80 context rows) sit in ONE 96-key tile; long ones stream 64-key tiles
     const bool single = p.Skv <= 96 && !(force & 16);
     const long blocks128 = (long)((p.Sq + 127) / 128) * p.H * p.B;
@@ -614,6 +911,7 @@ static int attn_dispatch(const LbAttnParams& pin, int force, hipStream_t s) {
     else if (single) { if (qg == 2) attn_launch<96, 2, 2>(p, s); else attn_launch<96, 1, 2>(p, s); }
     else if (force & 32) { if (qg == 2) attn_launch<64, 2, 5>(p, s); else attn_launch<64, 1, 5>(p, s); }
     else if (force & 256) { if (qg == 2) attn_launch<64, 2, 3>(p, s); else attn_launch<64, 1, 3>(p, s); }      // (rounds 1-5 streaming kernel: A/B)
+    else if (force & 512) { if (qg == 2) attn_launch_pp<2>(p, s); else attn_launch_pp<1>(p, s); }      // (ping-pong form, forced)
     else        { if (qg == 2) attn_launch_stream<2>(p, s); else attn_launch_stream<1>(p, s); }
     return lb_check_launch("lb_attn_fwd_d64");
 }

@@ -322,6 +322,8 @@ static int g_force_splitk = 0;    // 0 auto
 // 23.4 -> 21.9, 36.2 -> 34.0, 69.5 -> 64.4 us.
 static int g_t192_waves8 = 1;
 extern "C" void lb_gemm_set_t192_waves8(int on) { g_t192_waves8 = on; }
+static int g_kgroups = 1;         // 1 (default, round 6) = small unsplit 64x64 grids run two K-groups per block (tile code 11); 0 = never
+extern "C" void lb_gemm_set_kgroups(int on) { g_kgroups = on; }
 static int g_depth = 0;           // 0 = per-tile default ring depth, 1..4 = forced (A/B testing)
 extern "C" void lb_gemm_set_tuning(int tile, int splitk) { g_force_tile = tile; g_force_splitk = splitk; }
 extern "C" void lb_gemm_set_depth(int depth) { g_depth = depth; }
@@ -495,7 +497,7 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         const long b64 = blocks(64, 64);
         if (b64 > 256 && b64 <= 640 && blocks(128, 64) <= 256) tile = 2;
     }
-    const int bm = (tile == 7 || tile == 10) ? 192 : (tile >= 4 ? 256 : (tile == 3 ? 64 : 128));
+    const int bm = (tile == 7 || tile == 10) ? 192 : (tile == 11 ? 64 : (tile >= 4 ? 256 : (tile == 3 ? 64 : 128)));
     const int bn = (tile == 5 || tile == 9) ? 256 : ((tile == 1 || tile == 4 || tile == 7 || tile == 10) ? 128 : 64);
     const long nblk = blocks(bm, bn);
     int splitk = 1;
@@ -518,8 +520,14 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
         // written and read back) outweigh the operands.  Measured (profiles/r05_gemm_bench_call2.txt): M 4352, N 1280, K 2560 / 5120 on
         // the 256x128 tile = 39.1 / 75.1 us unsplit against 57.6 / 96.5 us with the 2 / 4 slices the "<= 256 blocks" rule above gave
         // them (120 such launches per transition).  The rule is meant for the 4-wave tiles of the M = 256..1024 programs.
-        if (tile >= 4 && !g_force_splitk) splitk = 1;
+        if (tile >= 4 && tile != 11 && !g_force_splitk) splitk = 1;
     }
+    // 64x64 grids that leave the chip a single wave per SIMD (<= 200 blocks, unsplit): two K-groups per block (tile code 11, gemm_glds.hip).
+    // MI355X, cold weights (profiles/r06_gemm_bench_call5.txt): M 512 x N 1280 x K 1280 (192 per B = 2 forward) 9.4 -> 7.9 us; grids with two
+    // or more blocks per CU lose (N 3840: 15.0 -> 18.1, GEGLU N 10240: 24.9 -> 42.9), as does a grid already split over K (K 5120).
+    if (!g_force_tile && g_kgroups && tile == 3 && splitk == 1 && !p.conv && g_variant == 1 && p.zero_page != nullptr && nblk <= 200 &&
+        (p.K + BK - 1) / BK >= 8)
+        tile = 11;
     tile_out = tile;
     splitk_out = splitk;
     nblk_out = nblk;
@@ -594,7 +602,7 @@ extern "C" int lb_gemm_f16(const LbGemmParams* pp, void* stream) {
     if (variant == 1) {
         lb_gemm_glds_init();                       // (wrapper runs at record time, never inside a capture)
         if (stages == 0)
-            stages = (tile == 3 || tile == 4 || tile == 7 || tile == 10) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
+            stages = (tile == 3 || tile == 4 || tile == 7 || tile == 10 || tile == 11) ? 3 : 2;   // 256x128: 3 x 48 KiB; 128x128 / 128x64: 2 stages; 64x64: 3 x 16 KiB
     }
     const dim3 grid((unsigned)nblk, 1, (unsigned)splitk);
     LB_DISPATCH("lb_gemm_f16", gemm_launch_impl(p, tile, depth, variant, stages, grid, s));

@@ -60,9 +60,16 @@ __device__ __forceinline__ void ln_accumulate(const f16x8 (&af)[TM], float (&sum
 // launch-bound B = 2 programs).  (A second form - statistics written by the PRODUCING GEMM's epilogue and only applied here -
 // was built in round 2, measured slower than the stand-alone LayerNorm at every batch size and removed in round 3:
 // profiles/r02_ln_stats_ab.txt, git history.)
-template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, int LNA = 0>
-__global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmParams p) {
-    constexpr int NT = WMW * 128;           // threads per block
+// KG (round 6): K-groups per block.  KG = 2: the block has TWO sets of 2 WMW waves; set g multiplies the K-tiles g, g + 2, ... of the
+// block's output tile out of its own LDS ring, and the two partial accumulators are added through LDS before the epilogue.  For the
+// launch-bound programs (B <= 4: M = 512 rows -> 160 blocks of 64x64 on 256 CUs, ONE wave per SIMD): a lone wave runs its K-tile as one
+// dependent chain - wait, barrier, fragment reads, 8 MFMAs, four requests - ~950 cycles for 128 cycles of matrix work, and nothing else
+// is resident to fill the gaps; a second wave per SIMD working on the other half of K doubles what is in flight per CU without
+// another launch, another slab round trip or more blocks.  Not bit-identical to KG = 1 (two partial sums per output instead of one chain).
+template <int BM, int BN, bool CONV, bool GEGLU, int S, int WMW, int LNA = 0, int KG = 1>
+__global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbGemmParams p) {
+    static_assert(KG == 1 || !CONV, "K-groups: plain / GEGLU GEMMs only");
+    constexpr int NT = WMW * 128;           // threads per K-group (= per block when KG == 1)
     constexpr int RPI = NT / 8;             // tile rows covered by one round of wave instructions
     constexpr int AI = BM * 8 / NT;         // wave instructions (16-B chunks per thread) of A per K-tile
     constexpr int WI = (BN * 8 + NT - 1) / NT;
@@ -72,9 +79,11 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
     static_assert(BM * 8 % NT == 0, "A tile rows must be a whole number of staging rounds");
     constexpr int TM = WROWS / 16, TN = BN / 32;
     constexpr int STAGE = (BM + WPAD) * BK; // halves per ring stage
-    extern __shared__ __attribute__((aligned(16))) f16 lds[];
+    extern __shared__ __attribute__((aligned(16))) f16 lds_all[];
 
-    const int tid = threadIdx.x;
+    const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT) : 0;      // (wave-uniform)
+    const int tid = KG > 1 ? (int)threadIdx.x - kgrp * NT : (int)threadIdx.x;
+    f16* const lds = lds_all + kgrp * (S * STAGE);
     const int lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int g = lane >> 4, l16 = lane & 15;
@@ -110,7 +119,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
     int a_iy[AI], a_ix[AI];
     bool a_ok[AI];
     int ci = 0, ky = 0, kx = 0;
-    int kcur = kt_begin * BK + cl * 8;
+    int kcur = (kt_begin + kgrp) * BK + cl * 8;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
         const int m = m0 + row0 + i * RPI;
@@ -177,7 +186,7 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
     };
     // advance this thread's K position (and conv tap state) by one K-tile
     auto advance_k = [&]() {
-        kcur += BK;
+        kcur += BK * KG;
         if (CONV) {
             ci += BK;
             if (p.Cin >= BK) {
@@ -249,7 +258,8 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
     // (tools/gemm_ablate.py: 5-13 % on the plain / GEGLU contractions, first > 1 PFLOP/s at 8192^3.)
     constexpr int HM = TM > 1 ? TM / 2 : 1;
     int st = 0;                               // ring stage of tile t
-    for (int t = 0; t < nkt; ++t) {
+    const int nloop = KG > 1 ? (nkt + KG - 1) / KG : nkt;      // (every K-group runs the same number of barriers; tiles past k_end are zero tiles)
+    for (int t = 0; t < nloop; ++t) {
         wait_vm_barrier<(S - 2) * NL>();      // tile t landed everywhere; stage (t-1)%S free everywhere
         int refill = st - 1;
         if (refill < 0) refill += S;
@@ -300,6 +310,49 @@ __global__ void __launch_bounds__(WMW * 128) gemm_f16_glds_kernel(const LbGemmPa
         st = st + 1 == S ? 0 : st + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before exit/epilogue
+
+    if constexpr (KG > 1) {
+        // partial accumulators (and LayerNorm row sums) of K-groups 1.. -> LDS -> added by K-group 0 in group order, which alone
+        // runs the epilogue.  Slot layout [wave][i][j][lane] x 16 B: every lane re-reads exactly the slot its twin wrote.
+        __syncthreads();                                            // every group is done with its ring
+        float* red = reinterpret_cast<float*>(lds_all);
+        constexpr int SLOT = (TM * TN * 4 + 2 * TM) * 64;           // floats per wave
+        if (kgrp > 0) {
+            float* mine = red + ((kgrp - 1) * (NT / 64) + wave) * SLOT;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(mine + ((i * TN + j) * 64 + lane) * 4) = acc[i][j];
+            if (LNA) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    mine[TM * TN * 256 + (2 * i) * 64 + lane] = ln_sum[i];
+                    mine[TM * TN * 256 + (2 * i + 1) * 64 + lane] = ln_sq[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (kgrp > 0) return;
+#pragma unroll
+        for (int gk = 1; gk < KG; ++gk) {
+            const float* theirs = red + ((gk - 1) * (NT / 64) + wave) * SLOT;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * TN + j) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += o[r];
+                }
+            if (LNA) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ln_sum[i] += theirs[TM * TN * 256 + (2 * i) * 64 + lane];
+                    ln_sq[i] += theirs[TM * TN * 256 + (2 * i + 1) * 64 + lane];
+                }
+            }
+        }
+    }
 
     // ---- epilogue (identical to gemm.hip) ----
     if (p.splitk > 1) {
@@ -360,6 +413,19 @@ constexpr int glds_stage_rows() {                       // A rows + weight rows 
     return BM + WI * RPI;
 }
 
+// K-group form (KG = 2) of a plain / GEGLU / LayerNorm-folded GEMM tile
+template <int BM, int BN, int S, int WMW, int KG>
+static int launch_glds_kgroups(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
+    const size_t smem = (size_t)KG * S * glds_stage_rows<BM, BN, WMW>() * BK * sizeof(f16);
+    const bool geglu = (p.flags & LB_GEMM_GEGLU) != 0, lna = (p.flags & LB_GEMM_LN_A) != 0;
+    const dim3 block(WMW * 128 * KG);
+    if (geglu && lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 1, KG>), grid, block, smem, stream, p);
+    else if (geglu) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, true, S, WMW, 0, KG>), grid, block, smem, stream, p);
+    else if (lna) hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 1, KG>), grid, block, smem, stream, p);
+    else hipLaunchKernelGGL((gemm_f16_glds_kernel<BM, BN, false, false, S, WMW, 0, KG>), grid, block, smem, stream, p);
+    return 0;
+}
+
 template <int BM, int BN, int S, int WMW = 2>
 static int launch_glds_variant(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t smem = (size_t)S * glds_stage_rows<BM, BN, WMW>() * BK * sizeof(f16);
@@ -400,6 +466,13 @@ void lb_gemm_glds_init() {
     allow_lds<256, 256, 2, 4>();
     allow_lds<192, 128, 3, 3>();
     allow_lds<192, 128, 3, 4>();
+    {   // 64x64, two K-groups: 2 x 3 x 16 KiB
+        const int smem = 2 * 3 * glds_stage_rows<64, 64, 2>() * BK * (int)sizeof(f16);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<64, 64, false, true, 3, 2, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<64, 64, false, true, 3, 2, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<64, 64, false, false, 3, 2, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_glds_kernel<64, 64, false, false, 3, 2, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
 }
 
 // tile: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, 64x128 per wave),
@@ -413,6 +486,10 @@ void lb_gemm_glds_init() {
 int lb_gemm_launch_glds(const LbGemmParams& p, int tile, int stages, dim3 grid, hipStream_t stream) {
     if (tile == 7) return launch_glds_variant<192, 128, 3, 3>(p, grid, stream);            // 3 x 42 KiB
     if (tile == 10) return launch_glds_variant<192, 128, 3, 4>(p, grid, stream);           // 8 waves x (48 x 64): 3 x 40 KiB
+    if (tile == 11) {                                                                      // 64x64, two K-groups of 4 waves (no conv form)
+        if (p.conv) return launch_glds_variant<64, 64, 3, 2>(p, grid, stream);
+        return launch_glds_kgroups<64, 64, 3, 2, 2>(p, grid, stream);
+    }
     if (tile == 5) return launch_glds_variant<256, 256, 2, 4>(p, grid, stream);     // 128 KiB: two stages only
     if (tile == 4) {
         if (stages == 3) return launch_glds_variant<256, 128, 3, 4>(p, grid, stream);

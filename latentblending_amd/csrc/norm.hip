@@ -268,6 +268,133 @@ static int groupnorm_chunked(const void* x, void* y, const float* gamma, const f
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: ONE-launch GroupNorm for feature maps whose (sample, channel slab) fits the registers of one block - the UNet's 16^2 and
+// 32^2 levels (33 of its 46 GroupNorms; 1.3 ms per B = 17 forward and 0.8 ms per B = 2 forward as partial + apply launches).  A block owns
+// one sample and a slab of SL = lcm(8, C / groups) channels (whole groups AND whole 16-byte vectors: 40, 80 or 120 channels), i.e.
+// vps = SL / 8 vectors per pixel; thread (r = tid / vps, slot = tid % vps) keeps the vectors of pixels r, r + rows, ... (at most NPX of
+// them, raw fp16) in registers.  Every request of the slab - and gamma / beta - is in flight at once; the statistics go per thread in fp32
+// (<= NPX values per channel), then in float64 through LDS (rows, then the channels of a group), the same E[x^2] - E[x]^2 form in double
+// as the two-launch path; the apply pass runs out of the registers: x is read ONCE, nothing but y is written.
+// ------------------------------------------------------------------------------------------
+template <int NPX>
+__global__ void __launch_bounds__(256) gn_fused_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, f16* __restrict__ y, int HW, int C, int ldx,
+                                                       int ldy, int cpg, int SL, float eps, int silu) {
+    extern __shared__ __attribute__((aligned(16))) double gnf_lds[];       // [2][rows][SL] doubles, then [2][SL], then mean / rstd per group
+    const int vps = SL >> 3, rows = 256 / vps;
+    const int tid = threadIdx.x, b = blockIdx.y, c_slab = blockIdx.x * SL;
+    const bool active = tid < rows * vps;
+    const int r = active ? tid / vps : 0, slot = active ? tid - r * vps : 0;
+    const int c0 = c_slab + slot * 8;
+    const f16* src = x + ((long)b * HW) * ldx + c0;
+    f16x8 raw[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {             // (pixels past HW re-read the last one: weighted out of the sums, stored nowhere)
+        const int px = min(r + k * rows, HW - 1);
+        raw[k] = *reinterpret_cast<const f16x8*>(src + (long)px * ldx);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    float sm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const bool ok = active && r + k * rows < HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = ok ? (float)raw[k][e] : 0.f;
+            sm[e] += v;
+            sq[e] += v * v;
+        }
+    }
+    double* lsum = gnf_lds;                     // [rows][SL]
+    double* lsq = gnf_lds + rows * SL;
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            lsum[r * SL + slot * 8 + e] = (double)sm[e];
+            lsq[r * SL + slot * 8 + e] = (double)sq[e];
+        }
+    }
+    __syncthreads();
+    double* csum = gnf_lds + 2 * rows * SL;     // [2][SL]: per channel, over the rows (fixed order)
+    if (tid < 2 * SL) {
+        const double* col = (tid < SL ? lsum : lsq) + (tid < SL ? tid : tid - SL);
+        double a = 0;
+        for (int rr = 0; rr < rows; ++rr) a += col[rr * SL];
+        csum[tid] = a;
+    }
+    __syncthreads();
+    const int ngrp = SL / cpg;                  // groups of this slab (1, 2 or 4)
+    float* stat = reinterpret_cast<float*>(csum + 2 * SL);      // [ngrp][2]: mean, rstd
+    if (tid < ngrp) {
+        double a = 0, q = 0;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += csum[c]; q += csum[SL + c]; }
+        const double cnt = (double)HW * cpg;
+        const double mean = a / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stat[2 * tid] = (float)mean;
+        stat[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int grp = (slot * 8 + e) / cpg;
+        const float gam = e < 4 ? g0[e & 3] : g1[e & 3], bet = e < 4 ? b0[e & 3] : b1[e & 3];
+        const float a = stat[2 * grp + 1] * gam;
+        sc[e] = a;
+        sh[e] = bet - stat[2 * grp] * a;
+    }
+    f16* dst = y + ((long)b * HW) * ldy + c0;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int px = r + k * rows;
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = __builtin_fmaf((float)raw[k][e], sc[e], sh[e]);
+            if (silu) t = lb_silu(t);
+            o[e] = (f16)t;
+        }
+        if (px < HW) *reinterpret_cast<f16x8*>(dst + (long)px * ldy) = o;
+    }
+}
+
+static int g_gn_fused = 1;      // 1 = the one-launch form wherever a (sample, slab) fits a block's registers (round 6), 0 = always partial + apply
+extern "C" void lb_groupnorm_set_fused(int on) { g_gn_fused = on; }
+
+// slab width (channels) and pixels per thread of the one-launch form; 0 = not eligible
+static int gn_fused_plan(int HW, int C, int groups, int x_is_f32, int* npx_out) {
+    if (!g_gn_fused || x_is_f32) return 0;
+    const int cpg = C / groups;
+    int SL = cpg;
+    while (SL % 8) SL += cpg;                   // lcm(8, cpg)
+    if (SL > 120 || C % SL) return 0;
+    const int rows = 256 / (SL / 8);
+    const int npx = (HW + rows - 1) / rows;
+    if (npx > 24) return 0;
+    *npx_out = npx <= 8 ? 8 : (npx <= 16 ? 16 : 24);
+    return SL;
+}
+
+static int groupnorm_fused(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int ldx, int ldy,
+                           int groups, float eps, int silu, int SL, int npx, hipStream_t s) {
+    const int cpg = C / groups, rows = 256 / (SL / 8);
+    const size_t smem = (size_t)(2 * rows * SL + 2 * SL) * sizeof(double) + 16 * sizeof(float);
+    const dim3 grid(C / SL, B);
+#define LB_GNF_ARGS (const f16*)x, gamma, beta, (f16*)y, HW, C, ldx, ldy, cpg, SL, eps, silu
+    if (npx == 8) hipLaunchKernelGGL(gn_fused_kernel<8>, grid, dim3(256), smem, s, LB_GNF_ARGS);
+    else if (npx == 16) hipLaunchKernelGGL(gn_fused_kernel<16>, grid, dim3(256), smem, s, LB_GNF_ARGS);
+    else hipLaunchKernelGGL(gn_fused_kernel<24>, grid, dim3(256), smem, s, LB_GNF_ARGS);
+#undef LB_GNF_ARGS
+    return lb_check_launch("lb_groupnorm_nhwc(fused)");
+}
+
 extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta,
                                  void* workspace, int B, int HW, int C, int ldx, int ldy, int groups,
                                  float eps, int silu, int x_is_f32, void* stream) {
@@ -275,6 +402,9 @@ extern "C" int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, con
     LB_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "lb_groupnorm_nhwc: C/ld multiple of 8");
     LB_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, "lb_groupnorm_nhwc: groups");
     LB_REQUIRE(C <= 4096, "lb_groupnorm_nhwc: C <= 4096");
+    int npx = 0;
+    const int SL = gn_fused_plan(HW, C, groups, x_is_f32, &npx);
+    if (SL) LB_DISPATCH("lb_groupnorm_nhwc", groupnorm_fused(x, y, gamma, beta, B, HW, C, ldx, ldy, groups, eps, silu, SL, npx, s));
     LB_DISPATCH("lb_groupnorm_nhwc", groupnorm_chunked(x, y, gamma, beta, workspace, B, HW, C, ldx, ldy, groups,
                                                        eps, silu, x_is_f32, s));
 }

@@ -634,7 +634,8 @@ def test_gemm_tile_policy_is_pinned():
     """lb_gemm_plan (pure host arithmetic of the launcher): the tile / split-K choices the MI355X sweeps led to
     (profiles/r01_gemm_*.txt, tools/ab_policy.py, profiles/r04_gemm_bench_call*.txt) for the shapes the SDXL programs launch.
     Tiles: 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128 (8 waves), 5 = 256x256 (8 waves, lock-step), 7 = 192x128 (6 waves, rounds 2-5),
-    9 = 256x256 ping-pong (gemm_pp.hip), 10 = 192x128 as 8 waves of 48x64 (round 6: every SIMD issues the same number of MFMAs)."""
+    9 = 256x256 ping-pong (gemm_pp.hip), 10 = 192x128 as 8 waves of 48x64 (round 6: every SIMD issues the same number of MFMAs),
+    11 = 64x64 with two K-groups of 4 waves per block (round 6: small unsplit grids)."""
     from latentblending_amd.hip import lib
 
     def plan(M, N, K, conv=False, geglu=False, ws=None, zero_page=True):
@@ -681,7 +682,7 @@ def test_gemm_tile_policy_is_pinned():
     assert conv_plan(17, 64, 320, 4) == (8, 17 * 16)                        # UNet conv_out
     assert conv_plan(17, 64, 320, 320)[0] == 6                              # ordinary widths: halo-tile kernel
     # UNet at B=2 (M = 512 / 2048): small tiles, split-K where K is long
-    assert plan(512, 1280, 1280) == (3, 1, 160)
+    assert plan(512, 1280, 1280) == (11, 1, 160)                        # round 6: two K-groups per 64x64 block where the grid leaves one wave per SIMD
     assert plan(512, 1280, 5120) == (3, 4, 160)
     assert plan(512, 1280, 11520, conv=True) == (3, 4, 160)
     assert plan(2048, 640, 5760, conv=True) == (2, 4, 160)              # 128x64 + split instead of 320 unsplittable blocks

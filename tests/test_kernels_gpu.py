@@ -413,9 +413,15 @@ def test_conv_resnet_epilogue(results_log):
 
 # ------------------------------------------------------------------ norms --------------------
 @pytest.mark.parametrize("case", [(1, 4096, 320, False), (2, 256, 2560, False), (1, 1024, 1920, False),
-                                  (1, 16384, 128, True), (2, 64, 32, False), (1, 4096, 512, True)])
+                                  (1, 16384, 128, True), (2, 64, 32, False), (1, 4096, 512, True),
+                                  # round 6, one-launch form (slab in registers): the UNet's 32^2 / 16^2 levels, a ragged pixel count
+                                  (3, 1024, 640, False), (2, 1024, 320, False), (3, 256, 1280, False), (2, 256, 1920, False),
+                                  (2, 1024, 1280, False), (2, 250, 640, False)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm(case, silu, results_log):
+    """fp32 torch reference; where the one-launch form applies it must also agree with the statistics + apply launches to rounding
+    (same float64 E[x^2] - E[x]^2, different fp32 partial sums: <= 2 fp16 ulps of the largest output)."""
+    from latentblending_amd.hip.lib import api
     o = ops()
     B, HW, C, f32_in = case
     x = rnd(B, HW, C, seed=45, scale=2.0, dtype=torch.float32 if f32_in else torch.float16)
@@ -426,6 +432,12 @@ def test_groupnorm(case, silu, results_log):
         ref = F.silu(ref)
     got = o.groupnorm_nhwc(x.to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu)
     check_close(results_log, f"groupnorm_{B}_{HW}_{C}_{int(f32_in)}_{int(silu)}", got, ref, floor=2e-3)
+    api.lb_groupnorm_set_fused(0)
+    try:
+        two = o.groupnorm_nhwc(x.to(DEV), gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu)
+    finally:
+        api.lb_groupnorm_set_fused(1)
+    assert float((got.float() - two.float()).abs().max()) <= 2.0 ** -9 * max(1.0, float(two.float().abs().max()))
 
 
 @pytest.mark.parametrize("shape", [(1024, 640), (256, 1280), (77, 2048), (5, 64), (4352, 1280), (131, 768), (9, 1032)])
@@ -449,7 +461,7 @@ def test_layernorm(shape, results_log):
     assert torch.equal(got.view(torch.int16), old.view(torch.int16))
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 11])
 @pytest.mark.parametrize("case", [(512, 1280, 1280, False), (4352, 3840, 1280, False), (1024, 5120, 640, True),
                                   (4352, 10240, 1280, True), (300, 192, 64, False)])
 def test_gemm_layernorm_fused(case, tile, results_log):
@@ -497,9 +509,10 @@ def test_attention_d64(case, results_log):
 
 # (49 / 50 = bit 5: the 5-stage-ring A/B form added at the end of round 3 without a GPU run: opt in with LB_TEST_EXPERIMENTAL=1)
 # (bit 6 = the former two-stage form of the one-tile kernel, bit 7 = 8-byte output stores instead of the paired 16-byte ones,
-#  bit 8 = the streaming kernel of rounds 1-5; without it streamed shapes run attn_fwd_d64_stream_kernel, round 6)
-@pytest.mark.parametrize("force", [1, 2, 17, 18, 65, 66, 129, 130, 257, 258, 273] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
-@pytest.mark.parametrize("case", [(2, 3, 300, 300, 300), (2, 2, 130, 80, 77), (1, 2, 70, 96, 90), (1, 1, 16, 8, 5)])
+#  bit 8 = the streaming kernel of rounds 1-5; without it streamed shapes run attn_fwd_d64_stream_kernel, round 6;
+#  bit 9 = the 8-wave ping-pong form attn_fwd_d64_pp_kernel, round 6; bit 11 = the block order of rounds 1-5)
+@pytest.mark.parametrize("force", [1, 2, 17, 18, 65, 66, 129, 130, 257, 258, 273, 513, 514, 529, 530, 2049, 2066] + ([49, 50] if os.environ.get("LB_TEST_EXPERIMENTAL") == "1" else []))
+@pytest.mark.parametrize("case", [(2, 3, 300, 300, 300), (2, 2, 130, 80, 77), (1, 2, 70, 96, 90), (1, 1, 16, 8, 5), (3, 7, 200, 200, 200)])
 def test_attention_d64_variants(case, force, results_log):
     """Every kernel variant (1 / 2 query groups per wave, single 96-key tile / streamed 64-key tiles) on ragged shapes,
     with Q, K and V read as column slices of ONE fused [tokens][3C] buffer (the UNet's layout)."""
@@ -529,7 +542,7 @@ def test_attention_d64_variants(case, force, results_log):
         assert float((wide.float() - got.float()).abs().max()) <= 2.0 ** -10 * max(1.0, float(got.float().abs().max()))
 
 
-@pytest.mark.parametrize("force", [0, 1, 2, 17])
+@pytest.mark.parametrize("force", [0, 1, 2, 17, 513, 530])
 @pytest.mark.parametrize("case", [(2, 12, 77), (1, 3, 200), (2, 2, 64)])
 def test_attention_causal(case, force, results_log):
     """Causal mask of the CLIP text towers (key k visible to query q iff k <= q), single-tile and streamed forms."""
@@ -559,9 +572,11 @@ def test_gemm_gelu_epilogues(results_log):
     check_close(results_log, "gemm_gelu_erf", got_g, F.gelu(y))
 
 
-def test_attention_spiked_scores(results_log):
-    """Force large running-max jumps between KV tiles (online-softmax rescale path)."""
-    o = ops()
+@pytest.mark.parametrize("force", [0, 256, 513])
+def test_attention_spiked_scores(force, results_log):
+    """Force large running-max jumps between KV tiles (online-softmax rescale path): streaming kernel (round 6), the rounds 1-5
+    kernel and the ping-pong form."""
+    o, l = ops(), lib()
     B, H, S = 1, 2, 256
     C = H * 64
     q, k, v = rnd(B, S, C, seed=54), rnd(B, S, C, seed=55), rnd(B, S, C, seed=56)
@@ -570,8 +585,12 @@ def test_attention_spiked_scores(results_log):
     k[0, :64] = -q[0, 5:6] * 5.0       # query 5: every score of the FIRST tile far below zero (the first tile sets the running maximum
     #                                    whatever its sign; the later tiles then raise it by ~2^60)
     ref = R.attention(q.float(), k.float(), v.float(), H)
-    got = o.attention_d64(q.reshape(S, C).to(DEV), k.reshape(S, C).to(DEV), v.reshape(S, C).to(DEV), B, H, S, S)
-    check_close(results_log, "attn_spiked", got.reshape(B, S, C), ref, floor=2e-3)
+    l.api.lb_attn_set_tuning(force)
+    try:
+        got = o.attention_d64(q.reshape(S, C).to(DEV), k.reshape(S, C).to(DEV), v.reshape(S, C).to(DEV), B, H, S, S)
+    finally:
+        l.api.lb_attn_set_tuning(0)
+    check_close(results_log, f"attn_spiked_f{force}", got.reshape(B, S, C), ref, floor=2e-3)
 
 
 @pytest.mark.parametrize("case", [(2, 1, 1024, 1024, 1024), (1, 1, 4096, 4096, 4096), (1, 2, 200, 200, 200), (2, 1, 100, 77, 70),
@@ -655,12 +674,12 @@ def test_small_kernels(results_log):
 
 # ------------------------------------------------------------------ direct-to-LDS GEMM variant
 @pytest.mark.parametrize("stages", [2, 3, 4])
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 10, 11])
 def test_gemm_glds_variant(tile, stages, results_log):
     """gemm_glds.hip (global_load_lds staging, S-stage LDS ring) against the same references.  Tile 10 (round 6) = the 192x128 tile
     as 8 waves of 48 x 64 (three 16-row MFMA tiles per wave)."""
-    if tile in (7, 10) and stages != 3:
-        pytest.skip("the 192x128 tiles have one ring depth (3)")
+    if tile in (7, 10, 11) and stages != 3:
+        pytest.skip("the 192x128 tiles and the two-K-group 64x64 tile have one ring depth (3)")
     o, l = ops(), lib()
     l.api.lb_gemm_set_variant(1, stages)
     l.api.lb_gemm_set_tuning(tile, 0)

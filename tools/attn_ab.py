@@ -1,7 +1,8 @@
 """Attention kernel variants on the UNet's B = 17 shapes (hipEvents over 50 back-to-back launches each, rotating over 4 buffer
 sets so that Q / O stream from HBM as they do inside the programs).  lb_attn_set_tuning: bits 0..1 = query groups per wave
 (1 / 2; 0 = by shape), bit 6 = the former two-stage form of the one-tile (cross-attention) kernel, bit 7 = 8-byte output stores,
-bit 8 (round 6) = the streaming kernel of rounds 1-5 instead of attn_fwd_d64_stream_kernel."""
+bit 8 (round 6) = the streaming kernel of rounds 1-5 instead of attn_fwd_d64_stream_kernel, bit 9 = the 8-wave ping-pong form,
+bit 11 = the block order of rounds 1-5 (query block fastest) instead of the XCD-aware one."""
 import os
 import sys
 
@@ -12,7 +13,7 @@ def main():
     import torch
     from latentblending_amd.hip import ops as o, lib as l
     DEV = "cuda"
-    for B in (17, 2):
+    for B in (17, 3, 2):
         for (H, S, kind) in [(10, 1024, "self"), (20, 256, "self"), (10, 1024, "cross"), (20, 256, "cross")]:
             Cc = H * 64
             sets = []
@@ -27,7 +28,7 @@ def main():
             outb = torch.empty(B * S, Cc, device=DEV, dtype=torch.float16)
             flops = 4.0 * B * H * S * (S if kind == "self" else 77) * 64
             ref, line = None, f"B={B:2d} H={H:2d} S={S:4d} {kind:5s}"
-            for force in ([0, 256, 1, 2, 257, 258] if kind == "self" else [0, 1, 2]):
+            for force in ([0, 2048, 256, 513, 514, 2048 + 513] if kind == "self" else [0, 2048, 1, 2]):
                 l.api.lb_attn_set_tuning(force)
                 try:
                     for i in range(8):

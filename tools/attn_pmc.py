@@ -12,10 +12,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def run():
     import torch
-    from latentblending_amd.hip import ops as o
+    from latentblending_amd.hip import ops as o, lib as l
     DEV = "cuda"
     B = 17
-    for (H, S, kind) in [(10, 1024, "self"), (20, 256, "self"), (10, 1024, "cross"), (20, 256, "cross")]:
+    l.api.lb_attn_set_tuning(int(os.environ.get("LB_ATTN_FORCE", "0")))       # (round 6: 0 = streaming kernel, 513 / 514 = ping-pong form, 256 = rounds 1-5)
+    shapes = [(10, 1024, "self"), (20, 256, "self"), (10, 1024, "cross"), (20, 256, "cross")]
+    if os.environ.get("LB_ATTN_SELF_ONLY"):
+        shapes = shapes[:2]
+    for (H, S, kind) in shapes:
         Cc = H * 64
         if kind == "self":
             qkv = torch.randn(B * S, 3 * Cc, device=DEV).half()

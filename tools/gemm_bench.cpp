@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
     if (set == "ksweep") shapes.insert(shapes.end(), std::begin(KSWEEP), std::end(KSWEEP));
-    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t7", 7, 1, 8}, {"t10", 10, 1, 8}, {"t1", 1, 1, 8}};
+    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t7", 7, 1, 8}, {"t10", 10, 1, 8}, {"t11", 11, 0, 8}, {"t3", 3, 0, 8}, {"t11-s1", 11, 1, 8}, {"t3-s1", 3, 1, 8}, {"t1", 1, 1, 8}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
     {

@@ -20,7 +20,11 @@ KNOBS = [("default", lambda: None),
          ("attention: r1-5 streaming kernel", lambda: lib.api.lb_attn_set_tuning(256)),
          ("layernorm: r1 kernel", lambda: lib.api.lb_layernorm_set_form(0)),
          ("192x128 tile: 6 waves", lambda: lib.api.lb_gemm_set_t192_waves8(0)),
-         ("all three as in round 5", lambda: (lib.api.lb_attn_set_tuning(256), lib.api.lb_layernorm_set_form(0), lib.api.lb_gemm_set_t192_waves8(0)))]
+         ("64x64 K-groups off", lambda: lib.api.lb_gemm_set_kgroups(0)),
+         ("groupnorm: statistics + apply launches", lambda: lib.api.lb_groupnorm_set_fused(0)),
+         ("attention: block order of r1-5", lambda: lib.api.lb_attn_set_tuning(2048)),
+         ("all as in round 5", lambda: (lib.api.lb_attn_set_tuning(256 + 2048), lib.api.lb_layernorm_set_form(0), lib.api.lb_gemm_set_t192_waves8(0),
+                                        lib.api.lb_gemm_set_kgroups(0), lib.api.lb_groupnorm_set_fused(0)))]
 
 
 def reset():
@@ -29,6 +33,8 @@ def reset():
     lib.api.lb_gemm_set_pp_auto(1)
     lib.api.lb_layernorm_set_form(1)
     lib.api.lb_gemm_set_t192_waves8(1)
+    lib.api.lb_gemm_set_kgroups(1)
+    lib.api.lb_groupnorm_set_fused(1)
 
 
 def timed(launch, iters):
