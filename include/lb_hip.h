@@ -67,8 +67,10 @@ int lb_euler_step_f16(const void* x, const void* eps, const void* noise, void* o
                       void* stream);
 /* diffusers DDIMScheduler.step, eta = 0, epsilon prediction (diffusers_holder.py:356 with a DDIM scheduler on the pipe; the
  * reference's SDXL pipes carry Euler schedulers, :42).  params_dev: float[batch][8] = {0, sqrt(abar_t), sqrt(abar_prev),
- * guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), -, -} - slot 0 = 0 makes lb_scale_model_input_f16 the identity, as DDIM's
- * scale_model_input is.  fp16 tensor arithmetic rounded op by op like diffusers' (no fp32 upcast in DDIM).  eps as above. */
+ * guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), 1 / sqrt(abar_t), -} - slot 0 = 0 makes lb_scale_model_input_f16 the identity, as
+ * DDIM's scale_model_input is; slot 6 is the fp32 reciprocal the kernel MULTIPLIES by where diffusers divides a device tensor by a
+ * 0-dim host tensor (the tensor library's true-division kernel multiplies by 1 / b for a host scalar b).  fp16 tensor arithmetic
+ * rounded op by op like diffusers' (no fp32 upcast in DDIM).  eps as above. */
 int lb_ddim_step_f16(const void* x, const void* eps, void* out, const float* params_dev, long per_sample, int batch,
                      int cfg, void* stream);
 

@@ -879,7 +879,7 @@ static void attn_launch(const LbAttnParams& p, hipStream_t s) {
     const size_t smem = (size_t)NS * 2 * KT * ATT_D * sizeof(f16);
     if constexpr (NS * 2 * KT * ATT_D * sizeof(f16) > 64 * 1024) {      // (beyond the default dynamic-LDS limit: the 5-stage A/B form)
         static unsigned long long seen = 0;
-        if (lb_first_call_on_device(seen))
+        LB_ONCE_PER_DEVICE(seen)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_d64_kernel<KT, QG, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     const dim3 grid((unsigned)((p.Sq + 64 * QG - 1) / (64 * QG)) * p.H * p.B);

@@ -256,7 +256,7 @@ extern "C" int lb_attn_fwd_d512(const LbAttnParams* pp, void* stream) {
     LB_REQUIRE(p.B < 65536 && p.H < 65536, "lb_attn_fwd_d512: grid limits");
     constexpr int SMEM = A5_NS * 2 * A5_KT * A5_D * (int)sizeof(f16);          // 128 KiB
     static unsigned long long seen = 0;
-    if (lb_first_call_on_device(seen))                  // (first call on a device happens at record time, outside any capture)
+    LB_ONCE_PER_DEVICE(seen)                  // (first call on a device happens at record time, outside any capture)
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_d512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     LB_DISPATCH_STMT("lb_attn_fwd_d512",
                      hipLaunchKernelGGL(attn_fwd_d512_kernel, dim3((p.Sq + 63) / 64, p.H, p.B), dim3(256), SMEM, s, p));

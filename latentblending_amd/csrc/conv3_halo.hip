@@ -398,7 +398,7 @@ static int launch_halo(const LbGemmParams& p, hipStream_t stream) {
     constexpr int HRP = (((TH + KS - 1) * (TW + KS - 1) + 7) / 8) * 8;
     constexpr int SMEM = (2 * HRP * 64 + 4 * BN * 64) * (int)sizeof(f16);
     static unsigned long long seen = 0;
-    if (lb_first_call_on_device(seen))                  // (first call on a device happens at record time, outside any capture)
+    LB_ONCE_PER_DEVICE(seen)                  // (first call on a device happens at record time, outside any capture)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<BN, TW, KS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     static_assert(BN == 128, "halo_grid assumes 128-channel blocks");

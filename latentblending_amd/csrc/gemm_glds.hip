@@ -458,7 +458,8 @@ static void allow_lds() {
 
 void lb_gemm_glds_init() {
     static unsigned long long seen = 0;
-    if (!lb_first_call_on_device(seen)) return;
+    LbFirstCallOnDevice once(seen);         // (held until every attribute below is set: a second thread waits here)
+    if (!once.first) return;
     allow_lds<128, 128, 2, 2>(); allow_lds<128, 128, 3>(); allow_lds<128, 128, 4>();
     allow_lds<128, 64, 2, 2>(); allow_lds<128, 64, 3>(); allow_lds<128, 64, 4>();
     allow_lds<64, 64, 2>(); allow_lds<64, 64, 3, 2>(); allow_lds<64, 64, 4>();

@@ -334,7 +334,7 @@ int lb_gemm_pp_eligible(const LbGemmParams& p) {
 template <bool GEGLU>
 static void pp_launch(const LbGemmParams& p, dim3 grid, hipStream_t stream) {
     static unsigned long long seen = 0;
-    if (lb_first_call_on_device(seen))
+    LB_ONCE_PER_DEVICE(seen)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_pp_kernel<GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     hipLaunchKernelGGL((gemm_f16_pp_kernel<GEGLU>), grid, dim3(512), PP_LDS_BYTES, stream, p);
 }

@@ -19,6 +19,7 @@ void lb_set_error(const char* what, hipError_t e);
 // ---- launch recording (program.hip) --------------------------------------------------------
 #ifdef __cplusplus
 #include <functional>
+#include <mutex>
 bool lb_recording();
 void lb_record(const char* name, std::function<int(hipStream_t)> fn);
 // Body of every extern "C" launcher: record a closure while a program is recording, otherwise
@@ -46,13 +47,26 @@ static inline int lb_check_launch(const char* what) {
 
 // "Once per DEVICE" guard for per-kernel attributes (hipFuncSetAttribute applies to the current device only: a process
 // that drives several GPUs must set it on each).  `seen` is the call site's own static bit mask (<= 64 devices).
-// (atomic test-and-set: two host threads recording programs at once must not both - or neither - see "first")
-static inline bool lb_first_call_on_device(unsigned long long& seen) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    return (__atomic_fetch_or(&seen, bit, __ATOMIC_ACQ_REL) & bit) == 0;
-}
+//     LB_ONCE_PER_DEVICE(seen) hipFuncSetAttribute(...);
+// The guard object holds one process-wide mutex for as long as the guarded statement runs: a second host thread that arrives while
+// the first is still inside hipFuncSetAttribute WAITS for it instead of launching with the attribute unset (round 5's atomic
+// test-and-set let the loser through at once: a launch asking for more than 64 KiB of dynamic LDS could then fail on that thread).
+struct LbFirstCallOnDevice {
+    std::unique_lock<std::mutex> lock;
+    bool first;
+    explicit LbFirstCallOnDevice(unsigned long long& seen) : lock(mutex()) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        first = (seen & bit) == 0;
+        seen |= bit;
+    }
+    static std::mutex& mutex() {
+        static std::mutex m;
+        return m;
+    }
+};
+#define LB_ONCE_PER_DEVICE(seen) if (LbFirstCallOnDevice lb_once_guard_{seen}; lb_once_guard_.first)
 
 #define LB_REQUIRE(cond, what)                                   \
     do {                                                         \

@@ -288,7 +288,7 @@ static int slerp_batched_impl(const void* p0, const void* p1, void* out, const d
     const size_t smem = 512 + (staged ? stage_bytes : 0);
     auto kern = slerp_batched_kernel<f16, 8>;
     static unsigned long long seen = 0;
-    if (lb_first_call_on_device(seen))
+    LB_ONCE_PER_DEVICE(seen)
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 512 + 128 * 1024);
     hipLaunchKernelGGL(kern, dim3((unsigned)npairs), dim3(512), smem, stream,
@@ -555,15 +555,18 @@ extern "C" int lb_euler_step_f16(const void* x, const void* eps, const void* noi
 // /root/reference/latentblending/diffusers_holder.py:356 when the pipe carries a DDIM scheduler (the reference's own SDXL
 // path constructs Euler schedulers, :42; north_star names "the Euler/DDIM step").
 //   params row: {0 (sigma of lb_scale_model_input_f16: DDIM's scale_model_input is the identity, x / sqrt(0 + 1) = x),
-//                sqrt(abar_t), sqrt(abar_prev), guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), -, -}
+//                sqrt(abar_t), sqrt(abar_prev), guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), 1 / sqrt(abar_t) [fp32], -}
 // diffusers does NOT upcast here (Euler does): sample and model_output are fp16 tensors, the coefficients 0-dim fp32 tensors,
 // so EVERY tensor operation rounds to fp16 -
-//   x0   = (sample - sqrt(1 - abar_t) * eps) / sqrt(abar_t)          [mul, sub, true division: three roundings]
+//   x0   = (sample - sqrt(1 - abar_t) * eps) / sqrt(abar_t)          [mul, sub, division: three roundings.  The divisor is a 0-dim HOST
+//                                                                     tensor: the device library's true-division kernel then computes
+//                                                                     a * (1 / b) with the fp32 reciprocal formed once - so does this
+//                                                                     kernel (slot 6 of the row), not a correctly rounded a / b]
 //   dir  = sqrt(1 - abar_prev) * eps                                 [one]
 //   prev = sqrt(abar_prev) * x0 + dir                                [mul, add: two]
 // and this kernel rounds in the same six places (CFG combine as in euler_one).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f16 ddim_one(f16 xh, f16 eu, f16 et, float sa_t, float sa_p, float sb_t, float sb_p, float g, bool cfg) {
+__device__ __forceinline__ f16 ddim_one(f16 xh, f16 eu, f16 et, float inv_sa_t, float sa_p, float sb_t, float sb_p, float g, bool cfg) {
     f16 e = eu;
     if (cfg) {
         const f16 diff = (f16)((float)et - (float)eu);
@@ -579,7 +582,7 @@ __device__ __forceinline__ f16 ddim_one(f16 xh, f16 eu, f16 et, float sa_t, floa
     };
     const f16 t1 = r16(__fmul_rn(sb_t, (float)e));
     const f16 t2 = r16(__fsub_rn((float)xh, (float)t1));
-    const f16 x0 = r16(__fdiv_rn((float)t2, sa_t));
+    const f16 x0 = r16(__fmul_rn((float)t2, inv_sa_t));
     const f16 dir = r16(__fmul_rn(sb_p, (float)e));
     const f16 t3 = r16(__fmul_rn(sa_p, (float)x0));
     return r16(__fadd_rn((float)t3, (float)dir));
@@ -590,7 +593,7 @@ __global__ void __launch_bounds__(256) ddim_step_kernel(const f16* __restrict__ 
                                                          const float* __restrict__ params, long per_sample, int batch) {
     const long total = per_sample * batch;
     for (int b = blockIdx.y; b < batch; b += gridDim.y) {
-        const float sa_t = params[b * LB_STEP_STRIDE + 1], sa_p = params[b * LB_STEP_STRIDE + 2], g = params[b * LB_STEP_STRIDE + 3];
+        const float sa_t = params[b * LB_STEP_STRIDE + 6], sa_p = params[b * LB_STEP_STRIDE + 2], g = params[b * LB_STEP_STRIDE + 3];      // (sa_t: the RECIPROCAL 1 / sqrt(abar_t))
         const float sb_t = params[b * LB_STEP_STRIDE + 4], sb_p = params[b * LB_STEP_STRIDE + 5];
         const long base = (long)b * per_sample;
         const long nvec = VEC ? per_sample >> 3 : 0;

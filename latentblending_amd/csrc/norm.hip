@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const f16* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float d = val[j][e] - mean;
-            q += ok[j] ? d * d : 0.f;
+            q = ok[j] ? __builtin_fmaf(d, d, q) : q;      // (the fused form layernorm_kernel's "q += d * d" contracts to: same bits)
         }
     const float rstd = rsqrtf(lb_wave_sum_dpp(q) / (float)C + eps);
 #pragma unroll

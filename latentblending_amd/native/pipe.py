@@ -105,12 +105,19 @@ class StableDiffusionXLPipeline:
                  text_encoder_fn=None, unet_native: Optional[NativeUNet] = None,
                  vae_native: Optional[NativeVAEDecoder] = None, allow_synthetic: Optional[bool] = None,
                  scheduler: Optional[str] = None):
-        """``scheduler``: None = the reference pipes' choice (Euler-ancestral for Turbo, Euler for base); "ddim" = diffusers'
-        DDIMScheduler (eta 0) behind the same native loops.
+        """``scheduler``: None or "euler" = the reference pipes' choice (Euler-ancestral for Turbo, Euler for base); "ddim" = diffusers'
+        DDIMScheduler (eta 0) behind the same native loops - also with ``turbo=True`` (the Turbo guidance / branching defaults
+        stay, only the sampler changes: deterministic, "leading" spacing).  Case-insensitive; anything else raises ``ValueError``
+        (a misspelt "DDIM " or a scheduler object used to fall through to Euler silently).
         ``allow_synthetic``: seeded synthetic stand-ins (UNet / VAE / LPIPS weights when no provider is given,
         prompt embeddings when no ``text_encoder_fn`` is given) are used silently when True (tests, bench: also
         ``LB_ALLOW_SYNTHETIC=1``); otherwise each stand-in announces itself ONCE with a ``UserWarning`` - frames
         rendered from them are noise-like and prompts have no semantic effect."""
+        if scheduler is not None and not isinstance(scheduler, str):
+            raise ValueError(f"NativeSDXLPipe: scheduler must be None, 'euler' or 'ddim' (got an object of type {type(scheduler).__name__})")
+        scheduler = None if scheduler is None else scheduler.strip().lower()
+        if scheduler not in (None, "euler", "ddim"):
+            raise ValueError(f"NativeSDXLPipe: unknown scheduler {scheduler!r} (None, 'euler' or 'ddim')")
         if not torch.cuda.is_available():
             raise RuntimeError("NativeSDXLPipe needs an MI355X (HIP device); there is no CPU fallback")
         self.device = torch.device(device)

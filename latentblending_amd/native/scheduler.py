@@ -180,10 +180,14 @@ class NativeDDIMScheduler:
         return self.alphas_cumprod[t], (self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod)
 
     def step_row(self, i: int, guidance: float = 0.0):
-        """(0, sqrt(abar_t), sqrt(abar_prev), guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev)) in fp32 tensor arithmetic, the
-        scalars diffusers forms inside DDIMScheduler.step (beta_prod_t ** 0.5, alpha_prod_t ** 0.5, ...)."""
+        """(0, sqrt(abar_t), sqrt(abar_prev), guidance, sqrt(1 - abar_t), sqrt(1 - abar_prev), 1 / sqrt(abar_t)) in fp32 tensor
+        arithmetic, the scalars diffusers forms inside DDIMScheduler.step (beta_prod_t ** 0.5, alpha_prod_t ** 0.5, ...).  The last
+        one is the fp32 reciprocal the device library forms when a tensor is divided by a 0-dim host tensor (its true-division
+        kernel multiplies by ``1 / b`` for a CPU scalar ``b``): ``lb_ddim_step_f16`` multiplies by it instead of dividing."""
         a_t, a_p = self.alpha_pair(i)
-        return (0.0, float(a_t ** 0.5), float(a_p ** 0.5), guidance, float((1 - a_t) ** 0.5), float((1 - a_p) ** 0.5))
+        sa_t = a_t ** 0.5
+        inv = torch.ones((), dtype=torch.float32) / sa_t.to(torch.float32)
+        return (0.0, float(sa_t), float(a_p ** 0.5), guidance, float((1 - a_t) ** 0.5), float((1 - a_p) ** 0.5), float(inv))
 
     def _locate(self, t) -> int:
         if self._step_index is None:

@@ -52,6 +52,9 @@ def _snapshot(be):
     return ({k: copy.copy(getattr(be, k)) for k in _ENGINE_FIELDS}, {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}, be._tree)
 
 
+_ENGINE_LOCKS_GUARD = threading.Lock()
+
+
 def _install(be, engine, holder, tree):
     for k, v in engine.items():
         setattr(be, k, v)
@@ -72,7 +75,13 @@ class EngineSession:
 
     def __init__(self, be, lock: Optional[threading.RLock] = None, noise_source=None, defaults=None):
         self.be = be
-        self._lock = lock if lock is not None else threading.RLock()
+        if lock is None:        # ONE lock per engine, shared by every router-less session of it (a lock per session would let two such
+            #                     sessions install themselves on the same engine from two threads at once)
+            with _ENGINE_LOCKS_GUARD:
+                lock = getattr(be, "_session_lock", None)
+                if lock is None:
+                    lock = be._session_lock = threading.RLock()
+        self._lock = lock
         self.noise_source = noise_source            # optional private ancestral-noise source (native pipes)
         if defaults is None:
             with self._lock:
@@ -101,20 +110,26 @@ class EngineSession:
                 raise RuntimeError("EngineSession.bound(): another session is bound to this engine on this thread - "
                                    "sessions do not nest (leave the first block before entering the second)")
             saved = _snapshot(be)
-            _install(be, self._engine, self._holder, self._tree)
-            be._bound_session = self
             sched = getattr(be.dh.pipe, "scheduler", None)
             swap_noise = self.noise_source is not None and hasattr(sched, "noise_source")
-            if swap_noise:
-                previous, sched.noise_source = sched.noise_source, self.noise_source
+            previous = sched.noise_source if swap_noise else None
+            be._bound_session = self
+            installed = False
             try:
+                # (inside the try: an install that raises half way - e.g. a step count the scheduler rejects - must not leave
+                #  part of this user's state on the shared engine)
+                _install(be, self._engine, self._holder, self._tree)
+                installed = True
+                if swap_noise:
+                    sched.noise_source = self.noise_source
                 yield be
             finally:
                 if swap_noise:
                     sched.noise_source = previous
-                self._engine = {k: getattr(be, k) for k in _ENGINE_FIELDS}
-                self._holder = {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}
-                self._tree = be._tree
+                if installed:                       # (a failed install leaves the session as it was)
+                    self._engine = {k: getattr(be, k) for k in _ENGINE_FIELDS}
+                    self._holder = {k: getattr(be.dh, k) for k in _HOLDER_FIELDS}
+                    self._tree = be._tree
                 be._bound_session = None
                 _install(be, *saved)                # the shared engine keeps nothing of this user
 

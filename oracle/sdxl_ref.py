@@ -380,7 +380,9 @@ class DDIMScheduler:
         sb_t, sa_t = float(beta_prod_t ** 0.5), float(alpha_prod_t ** 0.5)
         sb_p, sa_p = float((1 - alpha_prod_t_prev) ** 0.5), float(alpha_prod_t_prev ** 0.5)
         x, e = sample.float(), model_output.float()
-        x0 = rt(rt(x - rt(sb_t * e)) / sa_t)
+        # (division by a 0-dim HOST tensor: the device library multiplies by the fp32 reciprocal 1 / b, formed once)
+        inv = float(torch.ones((), dtype=torch.float32) / torch.tensor(sa_t, dtype=torch.float32))
+        x0 = rt(rt(x - rt(sb_t * e)) * inv)
         direction = rt(sb_p * e)
         return ((rt(sa_p * x0) + direction).to(torch.float16),)
 

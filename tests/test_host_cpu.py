@@ -137,6 +137,7 @@ def test_ddim_tables_and_step_match_closed_form():
         row = n.step_row(i, 2.5)
         at, ap = float(a_t), float(a_p)
         assert row[0] == 0.0 and row[3] == 2.5 and np.allclose(row[1:3] + row[4:6], [at ** 0.5, ap ** 0.5, (1 - at) ** 0.5, (1 - ap) ** 0.5], rtol=1e-6)
+        assert row[6] == float(np.float32(1.0) / np.float32(row[1]))       # the fp32 reciprocal the step multiplies by (host-scalar division)
         got = o.step(e, t, x)[0].double()
         want = ap ** 0.5 * (x.double() - (1 - at) ** 0.5 * e.double()) / at ** 0.5 + (1 - ap) ** 0.5 * e.double()
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
@@ -378,6 +379,11 @@ def test_product_path_has_no_cpu_fallback():
         import latentblending_amd.native as N
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             N.NativeSDXLPipe(turbo=True, unet_cfg=N.UNetConfig(**dataclasses.asdict(R.tiny_unet_cfg())))
+    # a scheduler name the pipe does not know is an error, not a silent Euler pipe (round-5 advice); checked before any device work
+    import latentblending_amd.native as N
+    for bad in ("dpm", "DDIM2", object()):
+        with pytest.raises(ValueError, match="scheduler"):
+            N.NativeSDXLPipe(turbo=True, scheduler=bad)
     # product modules never import the oracle
     for dirpath, _, files in os.walk(os.path.join(ROOT, "latentblending_amd")):
         for f in files:

@@ -223,3 +223,57 @@ def test_load_state_dict_resets_a_stale_negative_prompt(cpu_backend):
     assert dirty.negative_prompt is None and dirty.dh.negative_prompt == ""
     got = frames_of(dirty.run_transition())
     assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
+def test_failed_install_leaves_the_shared_engine_untouched(cpu_backend):
+    """Round-5 advice: an install that raises half way (here: a step count the holder rejects) must neither leave this user's
+    prompts / fields on the shared engine nor keep the engine marked as bound."""
+    from latentblending_amd import BlendingEngine, EngineSession
+    np.random.seed(0)
+    shared = BlendingEngine(tiny_pipe(True), metric=R.OracleLPIPS(7), verbose=False)
+    shared.set_prompt1("operator prompt")
+    s = EngineSession(shared)
+    with s.bound() as be:
+        be.set_prompt1("user prompt")
+    assert shared.prompt1 == "operator prompt"
+    good = s._holder["num_inference_steps"]
+    s._holder["num_inference_steps"] = "not a step count"
+    before = dict(prompt1=shared.prompt1, steps=shared.dh.num_inference_steps, guidance=shared.dh.guidance_scale)
+    with pytest.raises(Exception):
+        with s.bound():
+            pass
+    assert getattr(shared, "_bound_session", None) is None
+    assert dict(prompt1=shared.prompt1, steps=shared.dh.num_inference_steps, guidance=shared.dh.guidance_scale) == before
+    s._holder["num_inference_steps"] = good
+    with s.bound() as be:                       # the session itself survived the failed attempt
+        assert be.prompt1 == "user prompt"
+
+
+def test_router_less_sessions_of_one_engine_share_one_lock(cpu_backend):
+    """Two ``EngineSession(be)`` built without a router exclude each other: a second thread BLOCKS while the first is inside
+    ``bound()`` (a lock per session let both install themselves, or raised the "same thread" error from another thread)."""
+    from latentblending_amd import BlendingEngine, EngineSession
+    np.random.seed(0)
+    shared = BlendingEngine(tiny_pipe(True), metric=R.OracleLPIPS(7), verbose=False)
+    a, b = EngineSession(shared), EngineSession(shared)
+    assert a._lock is b._lock
+    inside, release, order, errors = threading.Event(), threading.Event(), [], []
+
+    def second():
+        try:
+            inside.wait(5)
+            with b.bound() as be:
+                order.append("b")
+                assert be._bound_session is b
+        except Exception as exc:       # pragma: no cover
+            errors.append(exc)
+
+    t = threading.Thread(target=second)
+    t.start()
+    with a.bound():
+        inside.set()
+        t.join(0.3)                                 # the second session is waiting for the lock, not raising
+        assert t.is_alive() and not errors
+        order.append("a")
+    t.join(5)
+    assert not errors and order == ["a", "b"]
