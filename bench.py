@@ -805,6 +805,13 @@ def _run():
                        "collectives_per_transition": farm.collectives / max(args.steps + args.warmup, 1),
                        "bytes_moved_per_transition": farm.bytes_moved / max(args.steps + args.warmup, 1),
                        "ms_per_transition_by_rank": per_rank_ms,
+                       # LB_FARM_TRACE=1: mean pack / collective / unpack milliseconds per farm call on rank 0 (the device is drained at
+                       # every boundary while tracing, so a traced run is slower than an untraced one: read the split, not the total)
+                       "trace_rank0": farm.trace_summary() if farm.trace_on else "set LB_FARM_TRACE=1 for the pack / collective / unpack split",
+                       "scale_workloads": {"cfg2 (default)": "--gpus N: 15 mid branches over N ranks (strong scaling; the metric's workload)",
+                                           "cfg4 (BASELINE configs[3], the config STATED for 8 GPUs)": "--gpus N --branches-total 64 --frontier 64: 64 mid "
+                                           "branches in one round, 8 per rank at N = 8 (B = 2 + 8 batches: the anchors' two small steps are 1/5 "
+                                           "of a rank's UNet time instead of 2/3 as in cfg 2 at N = 8)"},
                        "expected_strong_scaling": "Amdahl-limited by design: the two B=2 anchor steps (2 x 11.7 ms of a 151 ms transition on one GPU) "
                                                   "and the anchors' share of the B = 2 + G/N batches do not shard - about 2.3-2.5x at 8 GPUs for cfg 2 "
                                                   "(DESIGN.md section 5); --scaling weak (15 N branches) is the sharded regime"},

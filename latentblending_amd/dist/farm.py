@@ -25,6 +25,8 @@ the same branching plan before any collective whose shape depends on it is issue
 """
 from __future__ import annotations
 
+import os
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -41,8 +43,52 @@ class BranchFarm:
         self.device = torch.device(device) if device is not None else torch.device("cpu")
         self.bytes_moved = 0
         self.collectives = 0
+        self._send = {}             # (slots, slot bytes) -> preallocated packed send buffer of exchange_branches (reused round after round)
+        self._gather_into = True    # dist.all_gather_into_tensor (one contiguous receive buffer); falls back to the list form once if the backend lacks it
+        # LB_FARM_TRACE=1: wall-clock split of every exchange_branches / exchange_scalars / share_* call (pack / collective / unpack, the
+        # device drained at each boundary - so tracing costs the overlap it measures: diagnostics only).  bench.py prints it in its
+        # `farm` block, so that the first run on real xGMI explains itself.
+        self.trace_on = os.environ.get("LB_FARM_TRACE", "0") not in ("", "0")
+        self.trace: List[dict] = []
 
     # -- helpers ------------------------------------------------------------------------------
+    def _tick(self) -> float:
+        if self.trace_on and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return time.perf_counter()
+
+    def _trace(self, what: str, t0: float, t1: float, t2: float, t3: float, nbytes: int) -> None:
+        if self.trace_on:
+            self.trace.append({"op": what, "pack_ms": (t1 - t0) * 1e3, "collective_ms": (t2 - t1) * 1e3, "unpack_ms": (t3 - t2) * 1e3,
+                               "bytes_per_rank": int(nbytes)})
+
+    def trace_summary(self) -> dict:
+        """Per operation: calls and the mean pack / collective / unpack milliseconds (empty without LB_FARM_TRACE)."""
+        out = {}
+        for e in self.trace:
+            o = out.setdefault(e["op"], {"calls": 0, "pack_ms": 0.0, "collective_ms": 0.0, "unpack_ms": 0.0, "bytes_per_rank": e["bytes_per_rank"]})
+            o["calls"] += 1
+            for k in ("pack_ms", "collective_ms", "unpack_ms"):
+                o[k] += e[k]
+        for o in out.values():
+            for k in ("pack_ms", "collective_ms", "unpack_ms"):
+                o[k] = round(o[k] / o["calls"], 4)
+        return out
+
+    def _all_gather_packed(self, buf: torch.Tensor) -> torch.Tensor:
+        """``buf`` [slots, slot] uint8 of this rank -> [world, slots, slot] of every rank: ONE collective into ONE receive buffer."""
+        recv = torch.empty((self.world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+        if self._gather_into:
+            try:
+                dist.all_gather_into_tensor(recv, buf, group=self.group)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self._gather_into = False
+        if not self._gather_into:
+            dist.all_gather([recv[r] for r in range(self.world)], buf, group=self.group)
+        self.bytes_moved += buf.numel() * buf.element_size() * (self.world - 1)
+        self.collectives += 1
+        return recv
+
     def _all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
         t = t.to(self.device).contiguous()
         out = [torch.empty_like(t) for _ in range(self.world)]
@@ -142,33 +188,48 @@ class BranchFarm:
         slot = (lat_bytes + frm_bytes + 15) // 16 * 16
         slots = (n_total + self.world - 1) // self.world
         assert len(mine) == len(self.my_indices(n_total)), (len(mine), n_total, self.rank, self.world)
-        buf = torch.zeros(slots, slot, dtype=torch.uint8, device=self.device)
+        t0 = self._tick()
+        # the packed send buffer lives as long as the farm (round 5 allocated and zero-filled one per round, and staged every
+        # latent stack through a torch.stack temporary): latents and frame are copied straight into their slot
+        buf = self._send.get((slots, slot))
+        if buf is None:
+            if len(self._send) >= 8:
+                self._send.clear()
+            buf = self._send[(slots, slot)] = torch.zeros(slots, slot, dtype=torch.uint8, device=self.device)
         for k, (traj, frame) in enumerate(mine):
             live = [t for t in traj if t is not None]
             assert len(live) == active_steps, (len(live), active_steps)
-            lat = torch.stack([t.reshape(c, h, w) for t in live]).to(self.device, torch.float16).contiguous()
-            buf[k, :lat_bytes] = lat.view(torch.uint8).reshape(-1)
-            buf[k, lat_bytes:lat_bytes + frm_bytes] = self._frame_u8(frame).to(self.device).reshape(-1)
-        got = self._all_gather(buf)
+            dst = buf[k, :lat_bytes].view(torch.float16).view(active_steps, c, h, w)
+            for i, t in enumerate(live):
+                dst[i].copy_(t.reshape(c, h, w), non_blocking=True)
+            buf[k, lat_bytes:lat_bytes + frm_bytes].copy_(self._frame_u8(frame).reshape(-1), non_blocking=True)
+        t1 = self._tick()
+        got = self._all_gather_packed(buf)              # [world, slots, slot]: a fresh buffer, the views below keep it alive
+        t2 = self._tick()
         out = []
         for idx in range(n_total):
             r, k = idx % self.world, idx // self.world
-            row = got[r][k]
-            lat = row[:lat_bytes].clone().view(torch.float16).view(active_steps, 1, c, h, w)
+            row = got[r, k]
+            lat = row[:lat_bytes].view(torch.float16).view(active_steps, 1, c, h, w)
             traj = [None] * (total_steps - active_steps) + [lat[i] for i in range(active_steps)]
-            frm = row[lat_bytes:lat_bytes + frm_bytes].clone().view(fh, fw, 3)
-            out.append((traj, make_frame(frm)))
+            out.append((traj, make_frame(row[lat_bytes:lat_bytes + frm_bytes].view(fh, fw, 3))))
+        self._trace("exchange_branches", t0, t1, t2, self._tick(), slots * slot)
         return out
 
     def exchange_scalars(self, mine: Sequence[Sequence[float]], n_total: int, width: int = 2) -> List[List[float]]:
         """``mine``: ``width`` float64 values for each of ``my_indices(n_total)``; returns the values of all
         ``n_total`` branches in branch order, bit-identical on every rank (they are gathered, never recomputed)."""
         slots = (n_total + self.world - 1) // self.world
-        t = torch.zeros(slots, width, dtype=torch.float64)
-        for k, vals in enumerate(mine):
-            t[k] = torch.tensor([float(v) for v in vals], dtype=torch.float64)
-        got = [g.cpu() for g in self._all_gather(t)]
-        return [[float(v) for v in got[idx % self.world][idx // self.world].tolist()] for idx in range(n_total)]
+        t0 = self._tick()
+        rows = [[float(v) for v in vals] for vals in mine] + [[0.0] * width] * (slots - len(mine))
+        t = torch.tensor(rows, dtype=torch.float64).reshape(slots, width)         # ONE host tensor, one upload
+        t1 = self._tick()
+        got = self._all_gather_packed(t.to(self.device)).cpu()
+        t2 = self._tick()
+        vals = got.tolist()
+        out = [vals[idx % self.world][idx // self.world] for idx in range(n_total)]
+        self._trace("exchange_scalars", t0, t1, t2, self._tick(), slots * width * 8)
+        return out
 
     @staticmethod
     def _frame_u8(frame) -> torch.Tensor:

@@ -106,6 +106,9 @@ def scale_model_input(x: torch.Tensor, params: torch.Tensor, dup_for_cfg: bool =
 
 
 def euler_step(x, eps, params, noise=None, cfg=False, ancestral=False) -> torch.Tensor:
+    assert x.is_contiguous() and eps.is_contiguous(), "euler_step: the kernel takes its operands by pointer"
+    if noise is not None and not noise.is_contiguous():
+        noise = noise.contiguous()
     out = torch.empty_like(x)
     api.lb_euler_step_f16(x.data_ptr(), eps.data_ptr(), _ptr(noise), out.data_ptr(), params.data_ptr(),
                           x[0].numel(), x.shape[0], int(cfg), int(ancestral), stream_ptr())

@@ -490,8 +490,9 @@ class StableDiffusionXLPipeline:
             n_draw, keep = (G, list(range(G))) if noise_slots is None else (int(noise_slots[0]), list(noise_slots[1]))
             nm = steps - idx_injection
             flat = sched.draw_noise_many(A * steps + n_draw * nm, shape1, self.device)      # ONE launch on the device RNG
-            noise_a = flat[:A * steps].view(A, steps, *shape1[1:]).transpose(0, 1) if A else None          # [steps, A, 4, L, L]
-            noise_m = flat[A * steps:].view(n_draw, nm, *shape1[1:])[keep].transpose(0, 1) if G else None   # [nm, G, 4, L, L]
+            # (contiguous per step: the step kernels take noise[i] by pointer)
+            noise_a = flat[:A * steps].view(A, steps, *shape1[1:]).transpose(0, 1).contiguous() if A else None          # [steps, A, 4, L, L]
+            noise_m = flat[A * steps:].view(n_draw, nm, *shape1[1:])[keep].transpose(0, 1).contiguous() if G else None   # [nm, G, 4, L, L]
         lat_shape = (int(ref_start.shape[-3]), L, L)
         lat_a = torch.cat([s.to(self.device, F16).reshape(1, -1, L, L) for s in anchor_starts]).contiguous() if A else \
             torch.empty((0,) + lat_shape, dtype=F16, device=self.device)
