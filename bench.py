@@ -540,6 +540,18 @@ def secondary_lines(pipe, args, branches):
         dr = be.stats.get("speculation_dropped", 0) / 3
         out.append({"name": "cfg2 under a skewed metric (x exp(3 x position))", "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                     "frontier_rounds": be.stats.get("frontier_rounds", 0) / 3, "speculation_hit_rate": (ev - dr) / ev if ev else None})
+        # opt-in prior (BlendingEngine.speculate_from_previous_tree, round 6): the blind first round takes its 15 candidates from the
+        # commit order of the PREVIOUS transition on the engine instead of the level order of the binary splitting.  Every branch is
+        # still denoised / decoded / scored in the timed transition and the tree is the greedy tree; what is remembered is only which
+        # gaps the greedy order asked for last time.  Same skewed metric: ONE round instead of two (the warm-up transition sets the prior).
+        be.speculate_from_previous_tree = True
+        n, dt = timed(be, 3, 1)
+        ev = be.stats.get("speculation_evaluated", 0) / 3
+        dr = be.stats.get("speculation_dropped", 0) / 3
+        out.append({"name": "cfg2 under a skewed metric (x exp(3 x position)), speculate_from_previous_tree=True (the previous transition's commit "
+                            "order as the prior of the blind first round; opt-in)", "value": n / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                    "frontier_rounds": be.stats.get("frontier_rounds", 0) / 3, "speculation_hit_rate": (ev - dr) / ev if ev else None})
+        be.speculate_from_previous_tree = False
         # the same two metrics under TWO-STAGE speculation (BlendingEngine.two_stage_speculation: 7 branches with the anchors, then
         # 8 chosen from known distances): two rounds whatever the metric - the robust setting for real checkpoints
         for skew in (3.0, 0.0):

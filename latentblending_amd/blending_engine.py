@@ -84,6 +84,15 @@ class BlendingEngine:
         #                                     that fit HALF the stems (7 of 15) share the anchors' batches, the second round picks the
         #                                     rest best-first from the 8 gap distances then KNOWN: two rounds whatever the metric
         #                                     (tree identical either way: a gap's child does not depend on the order of evaluation)
+        self.speculate_from_previous_tree = False   # opt-in: the blind first round of a level (no distance known yet) takes its candidates
+        #                                     from the COMMIT ORDER of the same level of the previous transition on this engine (same
+        #                                     injection index and stem count) instead of the level order of the binary splitting.  A
+        #                                     prior, nothing more: every branch is still denoised, decoded and scored now, the tree is
+        #                                     the reference's greedy tree either way, a wrong prior costs what a blind guess costs today
+        #                                     (dropped speculation + another round).  Pays where consecutive transitions bend the tree
+        #                                     the same way (re-renders of one transition, a metric with a positional bias): the skewed
+        #                                     bench line needs ONE round instead of two
+        self._level_priors = {}             # (idx_injection, stems) -> [(f_left, f_right, f_mid)] in the order the level was committed
         self.fuse_anchor_round = True       # single-level trees: first round shares the anchors' UNet batches
         self.fuse_recycled_anchor = True    # ... also when an anchor is recycled (swap_forward chains, precomputed key frames): the
         #                                     fused wavefront takes the stored trajectory as given and denoises only the other one
@@ -592,6 +601,9 @@ class BlendingEngine:
                 w = 2 * w + 1               # complete levels of the binary splitting: 1, 3, 7, 15, ...
             width = min(width, w)
         gaps = self._bfs_midpoints(width)
+        prior = self._level_priors.get((idx_injection, stems)) if self.speculate_from_previous_tree and not self.two_stage_speculation else None
+        if prior is not None and len(prior) >= width:
+            gaps = list(prior[:width])          # (commit order of the previous transition: every gap's ends are 0, 1 or earlier midpoints)
         coeffs = planner.parental_crossfeed_coeffs(steps, idx_injection, self.parental_crossfeed_power,
                                                    self.parental_crossfeed_range, self.parental_crossfeed_decay)
         guid = [planner.damped_guidance(self.guidance_scale_base, self.guidance_scale_mid_damper, m) for _, _, m in gaps]
@@ -655,6 +667,9 @@ class BlendingEngine:
         tree = self._tree
         ready = dict(ready) if ready else {}     # (f_left, f_right) -> dict(fract, traj, frame, sl, sr)
         remaining = stems
+        committed_gaps = []                      # (f_left, f_right, f_mid) in commit order: next transition's prior (speculate_from_previous_tree)
+        prior = self._level_priors.get((idx_injection, stems)) if self.speculate_from_previous_tree else None
+        prior_rank = {(fl, fr): k for k, (fl, fr, _) in enumerate(prior)} if prior else {}
         last_committed = None                    # fraction of the branch the greedy order committed last at this level
         ratio_l, ratio_r = [], []                # measured (child-to-left-end, child-to-right-end) distance / parent gap distance
 
@@ -681,6 +696,7 @@ class BlendingEngine:
                     r = ready.pop(key)
                     learn(key, r, tree.similarities[gap])
                     tree.commit(r["fract"], idx_injection, r["traj"], r["frame"], r["sl"], r["sr"])
+                    committed_gaps.append((key[0], key[1], r["fract"]))
                     last_committed = r["fract"]
                     remaining -= 1
                     progressed = True
@@ -702,8 +718,15 @@ class BlendingEngine:
                     r_l, r_r = sorted(samples_l)[len(samples_l) // 2], sorted(samples_r)[len(samples_r) // 2]
             heap, tick = [], 0
             unscored = any(s is UNSCORED for s in tree.similarities)
+            blind_prior = unscored and bool(prior_rank)     # no distance known yet: rank gaps by the previous transition's commit order
+
+            def blind_estimate(a, b):                # earlier in the prior = larger estimate; gaps the prior never split come last
+                k = prior_rank.get((a, b))
+                return float(len(prior_rank) - k) if k is not None else -1.0
             for g in range(len(tree.fracts) - 1):
                 est = float("inf") if unscored else float(tree.similarities[g])
+                if blind_prior:
+                    est = blind_estimate(tree.fracts[g], tree.fracts[g + 1])
                 heap.append((-est, tick, tree.fracts[g], tree.fracts[g + 1], g))
                 tick += 1
             heapq.heapify(heap)
@@ -734,6 +757,8 @@ class BlendingEngine:
                             self.num_inference_steps, idx_injection, self.parental_crossfeed_power,
                             self.parental_crossfeed_range, self.parental_crossfeed_decay)))
                     est_l, est_r = -neg_est * r_l, -neg_est * r_r     # prediction until the child exists
+                if blind_prior:
+                    est_l, est_r = blind_estimate(fl, mid), blind_estimate(mid, fr)
                 if self.speculate_virtual:
                     for a, b, e in ((fl, mid, est_l), (mid, fr, est_r)):
                         heapq.heappush(heap, (-float(e), tick, a, b, g))
@@ -768,6 +793,8 @@ class BlendingEngine:
         # the greedy one).  The next transition's anchors are denoised under this value (compute_latents1 / 2, :370-423).
         if last_committed is not None:
             self.set_guidance_mid_dampening(last_committed)
+        if len(committed_gaps) == stems and stems > 0:
+            self._level_priors[(idx_injection, stems)] = committed_gaps
 
     def _gap_child_distances(self, triples, fracts):
         """[(child frame, left neighbour, right neighbour)], [(f_child, f_left, f_right)] -> [(d_left, d_right)].

@@ -840,6 +840,54 @@ def test_frontier_second_round_walks_the_predicted_greedy_order(skew, power, cpu
         assert other.stats["speculation_evaluated"] - other.stats.get("speculation_dropped", 0) == 15
 
 
+@pytest.mark.parametrize("skew", [3.0, -4.0])
+def test_previous_tree_as_speculation_prior(skew, cpu_backend):
+    """``speculate_from_previous_tree`` (opt-in, round 6): the blind first round of a level takes its candidates from the commit
+    order of the previous transition instead of the level order of the binary splitting.  Under a metric that bends the tree the
+    first transition needs two rounds (18 evaluated, 3 dropped); the second one - same metric - needs ONE (15 evaluated, none
+    dropped) and commits the identical (sequential) tree.  A prior from a DIFFERENT metric is only a worse guess: the tree is
+    still exact.  Off (default): every transition speculates blind."""
+    import math
+    from latentblending_amd import BlendingEngine
+
+    def metric(k):
+        return lambda a, b, fa, fb: abs(fa - fb) ** 2.0 * math.exp(k * 0.5 * (fa + fb))
+
+    def engine(width, prior):
+        p = tiny_pipe(turbo=True)
+        np.random.seed(0)
+        be = BlendingEngine(p, metric=R.OracleLPIPS(7), verbose=False, frontier_width=width)
+        be.speculate_from_previous_tree = prior
+        be.pair_metric = metric(skew)
+        be.set_dimensions((64, 64))
+        be.set_branching(nmb_max_branches=15)
+        be.set_prompt1("photo of a reef")
+        be.set_prompt2("rendering of an alien planet")
+        return be, p
+
+    def transition(be, p):
+        p.noise.reset()
+        be.stats.clear()
+        be.run_transition(fixed_seeds=[420, 421])
+        return list(be.tree_fracts), dict(be.stats)
+
+    seq, _ = transition(*engine(1, False))
+    be, p = engine(16, True)
+    first, st1 = transition(be, p)
+    second, st2 = transition(be, p)
+    assert first == seq and second == seq
+    assert st1["frontier_rounds"] >= 2 and st1["speculation_evaluated"] > 15
+    assert st2["frontier_rounds"] == 1 and st2["speculation_evaluated"] == 15 and st2.get("speculation_dropped", 0) == 0
+    be.pair_metric = metric(-skew)                  # the prior now points the wrong way: more rounds, the same exact tree
+    third, st3 = transition(be, p)
+    be1, p1 = engine(1, False)
+    be1.pair_metric = metric(-skew)
+    assert third == transition(be1, p1)[0] and st3["frontier_rounds"] >= 2
+    off, poff = engine(16, False)
+    transition(off, poff)
+    assert transition(off, poff)[1]["frontier_rounds"] == st1["frontier_rounds"]      # default: no memory between transitions
+
+
 @pytest.mark.parametrize("B,H,W,Cin,N,ks", [(17, 512, 512, 128, 128, 3), (17, 64, 64, 320, 320, 3), (17, 16, 16, 1280, 1280, 3),
                                             (2, 64, 64, 640, 320, 3), (17, 256, 256, 256, 256, 2), (3, 32, 32, 192, 640, 2),
                                             (1, 16, 16, 64, 64, 3)])
