@@ -247,10 +247,11 @@ def mixing_rooflines(device, G=15, L=64):
     ob = torch.empty_like(p0)
     us_big = _event_time_us(lambda: ops.slerp_strided(p0, p1, frb, n, out=ob), iters=5, warm=2)
     gbs = pairs * n * 6 / us_big / 1e3
-    # the figure to QUOTE is the rocprofv3-reported one of the committed run of tools/mixing_rocprof.py (kernel durations, not hipEvents
-    # around a host call); the live hipEvent number of this run is kept beside it
+    # `achieved` / `frac` are THIS run's measurement (hipEvents on the launch stream around the >= 1 GiB batch): a regression, another box
+    # or another commit shows up in them.  The rocprofv3-reported figure of the last committed run of tools/mixing_rocprof.py (kernel
+    # durations instead of hipEvents around a host call; usually ~15 % lower) is quoted beside it in its own field, tagged with its profile.
     rocprof = None
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_mixing_rocprof.json")) as fh:
                 k = next(k for k in json.load(fh)["kernels"] if "slerp_strided" in k["name"])
@@ -259,10 +260,9 @@ def mixing_rooflines(device, G=15, L=64):
         except Exception:
             continue
     out.append({"kernel": "slerp_strided_kernel (interpolate_spherical: parental mix / crossfeed)", "bound": "hbm",
-                "achieved": rocprof["GB_per_s"] if rocprof else gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (rocprof["GB_per_s"] if rocprof else gbs) / HBM_PEAK_GBS,
-                "achieved_source": "rocprofv3 kernel durations (committed profile)" if rocprof else "hipEvents of this run",
-                "rocprof_reported": rocprof, "hip_events_this_run": {"GB_per_s": gbs, "frac": gbs / HBM_PEAK_GBS},
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "achieved_source": "hipEvents of this run (launch stream, >= 1 GiB batch)",
+                "rocprof_reported": rocprof,
                 "algorithmic_bytes_per_element": 6, "batch": {"pairs": pairs, "elements_per_pair": n, "us": us_big},
                 "native_launch": {"pairs": G, "elements_per_pair": n, "us": us_native,
                                   "note": "one launch per denoising step of the wavefront: launch-latency bound"}})
@@ -292,11 +292,16 @@ def roofline_blocks(prof, launch_counts, device):
         "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F16_PEAK_TFLOPS,
         "traffic": _pmc_traffic_per_launch()[0],
         "traffic_measured_at": _pmc_traffic_per_launch()[1],
+        "measured_by": "hipEvents between the ops of an EAGER replay of the recorded launch programs, in this run (about 2-4 us of event boundary "
+                       "per op included: the conservative figure; the rocprofv3 kernel-duration figure of the committed run of the same command is in "
+                       "profiles/r06_rocprof_summary.json and is ~5 % higher)",
         "headroom_note": "like-for-like against the vendor library (rocBLAS gemm_ex, no epilogue operands on either side; "
-                         "profiles/r05_gemm_bench_call4.txt): at or ahead of it on 7 of the 10 program shapes, 12-18 % behind on "
-                         "M 4352 x N 1280 / 3840 at K 1280 / 2560 (its stream-K tiles balance 230 tiles over 256 CUs); PMC of the halo conv "
-                         "(profiles/r05_halo_pmc_lean_epilogue.json): matrix pipe 51 % busy on the VAE's big shapes, 65 % on the UNet's "
-                         "deep-K shape, 0.5 LDS instructions per MFMA, LDS pipe 25 % busy - wave time goes to vmcnt / barrier waits",
+                         "profiles/r06_gemm_bench_call2.txt, r05_gemm_bench_call4.txt): round 6 runs the 192x128 tile as 8 waves of 48x64 "
+                         "(every SIMD issues the same MFMA count): M 4352 x N 1280 at K 1280 / 2560 / 5120 = 21.9 / 34.0 / 64.4 us against the "
+                         "library's 19.2 / 33.8 / 95.7; still 10-14 % behind it on the two K = 1280 single-partial-round shapes (its stream-K tiles "
+                         "balance 230 tiles over 256 CUs); PMC of the halo conv (profiles/r05_halo_pmc_lean_epilogue.json): matrix pipe 51 % busy on "
+                         "the VAE's big shapes, 65 % on the UNet's deep-K shape, 0.5 LDS instructions per MFMA, LDS pipe 25 % busy - wave time goes "
+                         "to vmcnt / barrier waits",
         "traffic_unit": "HBM-side bytes per GEMM/conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                         "command committed in profiles/; null if absent)",
         "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
@@ -314,20 +319,23 @@ def roofline_blocks(prof, launch_counts, device):
     a = _tf(prof["attn_flops"], prof["attn_ms"])
     gn = _gbs(prof["gn_bytes"], prof["gn_ms"])
     rest = [
-        {"kernel": "attn_fwd_d64_kernel<KT,QG,NS> (UNet self + cross attention) + attn_fwd_d512_kernel (VAE mid block), in situ", "bound": "mfma", "achieved": a,
+        {"kernel": "attn_fwd_d64_stream_kernel<QG> (self-attention, round 6) + attn_fwd_d64_kernel<96,QG,1> (cross-attention, one tile) + "
+                   "attn_fwd_d512_kernel (VAE mid block), in situ", "bound": "mfma", "achieved": a,
          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F16_PEAK_TFLOPS,
+         "measured_by": "hipEvents between the ops of an eager replay, this run (PMC of the kernels: profiles/r06_attention_pmc.json)",
          "per_transition": {"tflop": prof["attn_flops"] / 1e12, "ms": prof["attn_ms"], "launches": prof["attn_launches"],
                             "self_TFLOPs": _tf(prof["attn_self_flops"], prof["attn_self_ms"]), "self_ms": prof["attn_self_ms"],
                             "cross_TFLOPs": _tf(prof["attn_cross_flops"], prof["attn_cross_ms"]), "cross_ms": prof["attn_cross_ms"]}},
-        {"kernel": "gn_partial_kernel + gn_apply_kernel / gn_fold_stats_kernel + gn_apply_kernel (GroupNorm + SiLU: 6 B per element, "
-                   "4 B where the producing conv's epilogue left the statistics)", "bound": "hbm",
+        {"kernel": "gn_partial_kernel + gn_apply_kernel / gn_fold_stats_kernel + gn_apply_kernel / gn_fused_kernel<NPX> (GroupNorm + SiLU: 6 B per "
+                   "element, 4 B where the producing conv's epilogue left the statistics or the one-launch form keeps the slab in registers)", "bound": "hbm",
          "achieved": gn, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gn / HBM_PEAK_GBS,
+         "measured_by": "hipEvents between the ops of an eager replay, this run",
          "per_transition": {"ms": prof["gn_ms"], "launches": prof["gn_launches"], "GB": prof["gn_bytes"] / 1e9}},
     ]
     if prof["ln_launches"]:
         ln = _gbs(prof["ln_bytes"], prof["ln_ms"])
-        rest.append({"kernel": "layernorm_kernel", "bound": "hbm", "achieved": ln, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ln / HBM_PEAK_GBS, "per_transition": {"ms": prof["ln_ms"], "launches": prof["ln_launches"]}})
+        rest.append({"kernel": "layernorm_rows_kernel<NV>", "bound": "hbm", "achieved": ln, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ln / HBM_PEAK_GBS, "measured_by": "hipEvents between the ops of an eager replay, this run", "per_transition": {"ms": prof["ln_ms"], "launches": prof["ln_launches"]}})
     else:
         rest.append({"kernel": "layernorm", "note": "no LayerNorm launch exists: folded into the consuming GEMMs (LB_GEMM_LN_A)"})
     try:
@@ -340,7 +348,7 @@ def roofline_blocks(prof, launch_counts, device):
 def _pmc_traffic_per_launch():
     """HBM traffic of the GEMM family from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE), per launch
     like `achieved`, and where that was measured (profile file, commit); PMC collection cannot run inside the timed bench."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json")
         try:
             with open(path) as fh:

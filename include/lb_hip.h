@@ -185,6 +185,7 @@ long lb_groupnorm_workspace_bytes(int B, int groups);
 int lb_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace,
                       int B, int HW, int C, int ldx, int ldy, int groups, float eps, int silu,
                       int x_is_f32, void* stream);
+int lb_groupnorm_plan(int HW, int C, int groups, int x_is_f32);   /* 1 = lb_groupnorm_nhwc runs this shape as one launch (x read once), 0 = statistics + apply launches; host arithmetic only */
 void lb_groupnorm_set_fused(int on);    /* testing: 1 (default) = lb_groupnorm_nhwc runs as ONE launch (slab in registers) wherever a (sample, lcm(8, C / groups)-channel slab) fits a block: <= 24 pixels per thread; 0 = always statistics + apply launches */
 int lb_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int M, int C,
                      int ldx, int ldy, float eps, void* stream);

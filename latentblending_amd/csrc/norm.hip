@@ -382,6 +382,11 @@ static int gn_fused_plan(int HW, int C, int groups, int x_is_f32, int* npx_out) 
     return SL;
 }
 
+extern "C" int lb_groupnorm_plan(int HW, int C, int groups, int x_is_f32) {       // 1 = lb_groupnorm_nhwc takes the one-launch form for this shape
+    int npx = 0;
+    return (groups > 0 && C > 0 && C % groups == 0 && C % 8 == 0 && gn_fused_plan(HW, C, groups, x_is_f32, &npx)) ? 1 : 0;
+}
+
 static int groupnorm_fused(const void* x, void* y, const float* gamma, const float* beta, int B, int HW, int C, int ldx, int ldy,
                            int groups, float eps, int silu, int SL, int npx, hipStream_t s) {
     const int cpg = C / groups, rows = 256 / (SL / 8);

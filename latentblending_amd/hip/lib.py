@@ -94,6 +94,7 @@ SIGNATURES = {
     "lb_attn_set_tuning": (None, [_i]),
     "lb_layernorm_set_form": (None, [_i]),
     "lb_groupnorm_set_fused": (None, [_i]),
+    "lb_groupnorm_plan": (_i, [_i, _i, _i, _i]),
     "lb_softmax_rows_f16": (_i, [_vp, _i, _i, _i, _f, _vp]),
     "lb_sinusoid_f16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "lb_copy_cols_f16": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
@@ -131,7 +132,7 @@ STUDY_SIGNATURES = {
 }
 
 _NO_CHECK = {"lb_version", "lb_last_error_string", "lb_gemm_workspace_bytes",
-             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_set_lean_epilogue", "lb_gemm_set_t192_waves8", "lb_gemm_set_kgroups", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_layernorm_set_form", "lb_groupnorm_set_fused", "lb_slerp_set_study", "lb_program_create",
+             "lb_groupnorm_workspace_bytes", "lb_groupnorm_set_l3_chunk", "lb_conv_halo_set_persistent", "lb_conv_halo_plan", "lb_gemm_ch_stat_rows", "lb_conv_halo_set_study", "lb_gemm_set_tuning", "lb_gemm_set_depth", "lb_gemm_set_variant", "lb_gemm_set_wide_store", "lb_gemm_set_lean_epilogue", "lb_gemm_set_t192_waves8", "lb_gemm_set_kgroups", "lb_gemm_pp_set_group", "lb_gemm_set_pp_auto", "lb_gemm_set_policy", "lb_gemm_set_halo", "lb_attn_set_tuning", "lb_layernorm_set_form", "lb_groupnorm_set_fused", "lb_groupnorm_plan", "lb_slerp_set_study", "lb_program_create",
              "lb_program_destroy", "lb_program_num_ops", "lb_program_op_name"}
 
 

@@ -254,8 +254,10 @@ class Emitter:
         api.lb_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                               self._gn_ws(B, groups).data_ptr(), B, HW, C_, ldx or C_, C_, groups, eps,
                               int(silu), int(x.dtype == F32), _stream())
-        # algorithmic traffic: the statistics pass reads x, the apply pass reads x and writes fp16 y
-        self.norm_log.append({"op": "lb_groupnorm_nhwc", "bytes": float(B * HW * C_) * (2 * x.element_size() + 2)})
+        # algorithmic traffic: the statistics pass reads x, the apply pass reads x and writes fp16 y; the one-launch form (round 6: slab in
+        # registers) reads x once
+        one = bool(api.lb_groupnorm_plan(HW, C_, groups, int(x.dtype == F32)))
+        self.norm_log.append({"op": "lb_groupnorm_nhwc", "bytes": float(B * HW * C_) * ((1 if one else 2) * x.element_size() + 2), "one_launch": one})
         return out
 
     def layernorm(self, x, out, gamma, beta, *, M: int, C_: int, eps: float = 1e-5):
