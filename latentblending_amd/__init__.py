@@ -9,7 +9,8 @@ from .utils import (interpolate_spherical, add_frames_linear_interp, interpolate
 
 from . import replay  # noqa: E402  (multi-transition driver + movie JSON)
 from .session import EngineSession, SessionRouter  # noqa: E402  (per-user state + router)
+from .frontend import BlendingVariableHolder, MultiUserRouter  # noqa: E402  (the Gradio page's logic without the widgets, §8f rank 4)
 
-__all__ = ["BlendingEngine", "replay", "EngineSession", "SessionRouter", "DiffusersHolder", "interpolate_spherical",
+__all__ = ["BlendingEngine", "replay", "EngineSession", "SessionRouter", "BlendingVariableHolder", "MultiUserRouter", "DiffusersHolder", "interpolate_spherical",
            "add_frames_linear_interp", "interpolate_linear", "get_spacing", "get_time",
            "yml_load", "yml_save"]

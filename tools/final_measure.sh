@@ -5,7 +5,7 @@
 #   3. tools/pmc_summary.py folds them into profiles/<tag>_rocprof_summary.json  (bench.py reads roofline.traffic from it)
 #   4. the bench line itself, cfg 2 (+ the secondary lines: skewed metric, cfg 3)
 # Raw traces are dropped after summarising (gpurun merges at most 64 MiB back).
-TAG=${1:-r04}
+TAG=${1:-r06}
 COMMIT=${2:-unknown}        # git rev-parse --short HEAD of the tree being measured (passed in: the GPU box has no .git)
 R=$PWD
 OUT=$R/gpurun_out
