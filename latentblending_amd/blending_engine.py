@@ -613,7 +613,7 @@ class BlendingEngine:
         first, last, mids = pipe.native_run_wavefront(
             [self.get_mixed_conditioning(0)[0], self.get_mixed_conditioning(1)[0]],
             [self.get_noise(self.seed1), self.get_noise(self.seed2)],
-            [self.get_mixed_conditioning(gaps[k][2])[0] for k in mine], [gaps[k][2] for k in mine],
+            (lambda: [self.get_mixed_conditioning(gaps[k][2])[0] for k in mine]), [gaps[k][2] for k in mine],     # (built behind the first launch)
             [coeffs] * len(mine), idx_injection, steps, self.guidance_scale, [guid[k] for k in mine],
             noise_slots=(len(gaps), mine) if farm else None, elide_dead_steps=self.elide_dead_steps and not farm,
             known_anchors=(self.tree_latents[0] if keep1 else None, self.tree_latents[-1] if keep2 else None))

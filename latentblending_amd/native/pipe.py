@@ -422,7 +422,12 @@ class StableDiffusionXLPipeline:
         the other anchor, the mids mix from the stored latents - and is returned as given."""
         known = [None if t is None else list(t) for t in known_anchors]
         live = [k for k in (0, 1) if known[k] is None]          # anchors denoised here
-        A, G = len(live), len(mid_conds)
+        # ``mid_conds`` may be a CALLABLE returning the list (round 6): the mids' conditionings (two lerp launches each) are then built -
+        # and the big batch's conditioning program launched - AFTER the first anchors-only step is on the stream, i.e. the host work runs
+        # beside 11 ms of GPU work instead of in front of it (a cfg-2 transition spent ~2 ms of host time before its first launch)
+        lazy_mids = callable(mid_conds)
+        A, G = len(live), len(mid_fracts)
+        assert lazy_mids or len(mid_conds) == G
         assert A + G > 0, "native_run_wavefront: nothing to denoise"
         assert all(t is None or len(t) == num_inference_steps for t in known), "known anchors must be full trajectories"
         anchor_conds = [anchor_conds[k] for k in live]
@@ -473,12 +478,16 @@ class StableDiffusionXLPipeline:
         # chip idle) and the main stream waits for it only before the first big step.  Different programs own different
         # arenas / workspaces, so the two streams share nothing but read-only weights.
         cond_ready = None
+        deferred = False
         if G and prog_a is not None and idx_injection > 0:
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
-            prog_all, cond_ready = prepared(list(anchor_conds) + list(mid_conds), side=self._side_stream)
+            if lazy_mids and A:
+                deferred, prog_all = True, None         # (prepared right behind the first small step's launch, below)
+            else:
+                prog_all, cond_ready = prepared(list(anchor_conds) + list(mid_conds() if lazy_mids else mid_conds), side=self._side_stream)
         else:
-            prog_all = prepared(list(anchor_conds) + list(mid_conds))[0] if G else prog_a
+            prog_all = prepared(list(anchor_conds) + list(mid_conds() if lazy_mids else mid_conds))[0] if G else prog_a
         stream = torch.cuda.current_stream().cuda_stream
         rows_a = [sched.step_row(i, all_g[0]) for i in range(steps)]
         par_a = ops.step_params([r for r in rows_a for _ in range(A)], self.device).view(steps, A, 8) if A else None
@@ -548,6 +557,9 @@ class StableDiffusionXLPipeline:
                 self.stats["unet_forwards"] += 1
                 self.stats["unet_samples"] += prog.B
                 out = sched.device_step(lat, prog.eps, params, noise=noise, cfg=cfg)
+                if deferred:            # the first small step is launched: now the host work the big batch needs (runs beside it)
+                    deferred = False
+                    prog_all, cond_ready = prepared(list(anchor_conds) + list(mid_conds()), side=self._side_stream)
                 lat_a = out[:A]
                 for j, k in enumerate(live):
                     traj_a[k].append(out[j:j + 1])
