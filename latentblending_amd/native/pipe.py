@@ -453,17 +453,26 @@ class StableDiffusionXLPipeline:
             neg_pool = torch.cat([c[3] for c in conds]).to(self.device, F16)
             return torch.cat([neg_ctx, pos_ctx]), torch.cat([neg_pool, pos_pool])
 
-        def prepared(conds, side=None):
+        def prepared(conds, side=None, after=None):
             # (the program - arena, workspaces, first-time graph instantiation - is always obtained on the MAIN stream: its
             # allocations then belong to the main stream's allocator pool; only the conditioning launches move to `side`)
-            prog = self.unet_program(len(conds) * mul, L)
+            # `conds` may be a callable (evaluated on the stream the conditioning launches run on); `after` = an event of the main
+            # stream the side stream waits for INSTEAD of everything queued on the main stream so far (the deferred form: the first
+            # small UNet step is already queued - waiting for it would also park the host in the side stream's host-to-device copies)
+            n_conds = A + G if callable(conds) else len(conds)
+            prog = self.unet_program(n_conds * mul, L)
             if side is None:
+                conds = conds() if callable(conds) else conds
                 ctx, pooled = conditioning(conds)
                 ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
                 prog.set_conditioning(ctx, pooled, ids)
                 return prog, None
-            side.wait_stream(torch.cuda.current_stream())
+            if after is not None:
+                side.wait_event(after)
+            else:
+                side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                conds = conds() if callable(conds) else conds
                 ctx, pooled = conditioning(conds)
                 ids = torch.tensor([self._time_ids_row()] * ctx.shape[0], dtype=F32, device=self.device)
                 prog.set_conditioning(ctx, pooled, ids)     # (copies into program-owned buffers, then the conditioning program: all
@@ -484,6 +493,8 @@ class StableDiffusionXLPipeline:
                 self._side_stream = torch.cuda.Stream(device=self.device)
             if lazy_mids and A:
                 deferred, prog_all = True, None         # (prepared right behind the first small step's launch, below)
+                before_first = torch.cuda.Event()
+                before_first.record()                   # everything the mids' conditionings read (the prompt embeddings) is older than this
             else:
                 prog_all, cond_ready = prepared(list(anchor_conds) + list(mid_conds() if lazy_mids else mid_conds), side=self._side_stream)
         else:
@@ -559,7 +570,7 @@ class StableDiffusionXLPipeline:
                 out = sched.device_step(lat, prog.eps, params, noise=noise, cfg=cfg)
                 if deferred:            # the first small step is launched: now the host work the big batch needs (runs beside it)
                     deferred = False
-                    prog_all, cond_ready = prepared(list(anchor_conds) + list(mid_conds()), side=self._side_stream)
+                    prog_all, cond_ready = prepared(lambda: list(anchor_conds) + list(mid_conds()), side=self._side_stream, after=before_first)
                 lat_a = out[:A]
                 for j, k in enumerate(live):
                     traj_a[k].append(out[j:j + 1])
