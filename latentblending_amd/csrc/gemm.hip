@@ -478,6 +478,11 @@ static void gemm_plan(const LbGemmParams& p, int& tile_out, int& splitk_out, lon
             }
         }
     }
+    // GEGLU projections of the small-batch programs (M 512 x N 10240, M 2048 x N 5120: 256x128 / 4-wave tiles until round 6): one round (or a short
+    // second one) of 8-wave 192x128 tiles - 24.9 -> 21.7 us and 28.2 -> 25.1 us, rocBLAS 22.3 / 25.1 (profiles/r06_gemm_bench_call14.txt).
+    if (!g_force_tile && g_t192_waves8 && geglu && !p.conv && (tile == 1 || tile == 2 || tile == 4) && p.M <= 2048 && g_variant == 1 &&
+        p.zero_page != nullptr && blocks(192, 128) <= 448 && p.K >= 512)
+        tile = 10;
     if (tile >= 4 && tile != 9 && (g_variant != 1 || p.zero_page == nullptr)) tile = 1;
     // Ping-pong 256x256 loop (gemm_pp.hip): 1.15-1.27x the lock-step 8-wave tiles wherever 256-wide tiles fill the chip and
     // the K loop is long enough to pay for its deeper prologue - on the B = 17 programs the GEGLU projections (M 4352 /

@@ -91,9 +91,9 @@ def lerp(p0: torch.Tensor, p1: torch.Tensor, fract: float) -> torch.Tensor:
 # ------------------------------------------------------------------------------ scheduler --
 def step_params(rows: Sequence[Sequence[float]], device) -> torch.Tensor:
     """rows of (sigma_from, sigma_next, sigma_up, guidance, dt) -> float32 [B, 8] on device."""
-    t = torch.zeros(len(rows), 8, dtype=F32)
-    for i, r in enumerate(rows):
-        t[i, :len(r)] = torch.tensor([float(v) for v in r], dtype=F32)
+    # (ONE host tensor from nested lists - a cfg-2 wavefront uploads 34 + 8 rows: the per-row tensor constructions of rounds 1-5 cost
+    #  ~0.1 ms of host time in front of a transition's first launch)
+    t = torch.tensor([[float(v) for v in r] + [0.0] * (8 - len(r)) for r in rows], dtype=F32).reshape(len(rows), 8)
     return t.to(device)
 
 

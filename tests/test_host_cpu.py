@@ -693,6 +693,7 @@ def test_gemm_tile_policy_is_pinned():
     assert plan(512, 1280, 11520, conv=True) == (3, 4, 160)
     assert plan(2048, 640, 5760, conv=True) == (2, 4, 160)              # 128x64 + split instead of 320 unsplittable blocks
     assert plan(2048, 640, 640) == (3, 1, 320)
+    assert plan(512, 10240, 1280, geglu=True) == (10, 1, 240) and plan(2048, 5120, 640, geglu=True)[0] == 10      # round 6: small-batch GEGLU on the 8-wave 192x128 tile
     assert plan(512, 1280, 5120, ws=False)[1] == 1                      # no slab workspace -> never splits
     # without the zero page the direct-to-LDS family (and its 8-wave tiles) is not available
     assert plan(4352, 1280, 5120, zero_page=False)[0] in (1, 2) and plan(4456448, 128, 1152, conv=True, zero_page=False)[0] == 1

@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     if (set == "b2" || set == "all") shapes.insert(shapes.end(), std::begin(B2), std::end(B2));
     if (set == "big" || set == "all") shapes.insert(shapes.end(), std::begin(BIG), std::end(BIG));
     if (set == "ksweep") shapes.insert(shapes.end(), std::begin(KSWEEP), std::end(KSWEEP));
-    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t7", 7, 1, 8}, {"t10", 10, 1, 8}, {"t11", 11, 0, 8}, {"t3", 3, 0, 8}, {"t11-s1", 11, 1, 8}, {"t3-s1", 3, 1, 8}, {"t1", 1, 1, 8}};
+    const Variant all_variants[] = {{"auto", 0, 0, 8}, {"auto-rowepi", 0, 0, 8, 0}, {"auto-noepi", 0, 0, 8, 1, 1}, {"pp", 9, 1, 8}, {"pp-g0", 9, 1, 0}, {"pp-g4", 9, 1, 4}, {"t5", 5, 1, 8}, {"t4", 4, 1, 8}, {"t7", 7, 1, 8}, {"t10", 10, 1, 8}, {"t11", 11, 0, 8}, {"t3", 3, 0, 8}, {"t11-s1", 11, 1, 8}, {"t3-s1", 3, 1, 8}, {"t1", 1, 1, 8}, {"t11-s2", 11, 2, 8}, {"t3-s2", 3, 2, 8}, {"t3-s8", 3, 8, 8}, {"t2", 2, 0, 8}, {"t2-s2", 2, 2, 8}, {"t2-s4", 2, 4, 8}, {"t2-s8", 2, 8, 8}, {"t1-s4", 1, 4, 8}, {"t1-s8", 1, 8, 8}, {"t10-s2", 10, 2, 8}};
     // GB_VARIANTS=auto,pp-m1 selects (the first one is the reference of the bit-identity check); GB_NOCHECK / GB_NOROCBLAS = 1 skip those parts
     std::vector<Variant> variants;
     {
