@@ -207,38 +207,20 @@ class MultiUserRouter:
     def user_overflow_protection(self):
         pass
 
-    def preview_img_selected(self, user_id, data, button=None):
-        return self.user_blendingvariableholder[user_id].preview_img_selected(data, button)
 
-    def movie_img_selected(self, user_id, data, button=None):
-        return self.user_blendingvariableholder[user_id].movie_img_selected(data, button)
+def _forward(name):
+    """Router method ``name(user_id, *args)`` -> the user's holder method ``name(*args)`` (gradio_ui.py:58-90: thirteen one-line forwards)."""
+    def call(self, user_id, *args):
+        return getattr(self.user_blendingvariableholder[user_id], name)(*args)
+    call.__name__ = name
+    call.__doc__ = f"``BlendingVariableHolder.{name}`` of user ``user_id``."
+    return call
 
-    def compute_imgs(self, user_id, prompt, negative_prompt):
-        return self.user_blendingvariableholder[user_id].compute_imgs(prompt, negative_prompt)
 
-    def get_list_images_movie(self, user_id):
-        return self.user_blendingvariableholder[user_id].get_list_images_movie()
-
-    def init_new_movie(self, user_id):
-        return self.user_blendingvariableholder[user_id].init_new_movie()
-
-    def write_json(self, user_id):
-        return self.user_blendingvariableholder[user_id].write_json()
-
-    def add_image_to_video(self, user_id):
-        return self.user_blendingvariableholder[user_id].add_image_to_video()
-
-    def img_movie_delete(self, user_id):
-        return self.user_blendingvariableholder[user_id].img_movie_delete()
-
-    def img_movie_later(self, user_id):
-        return self.user_blendingvariableholder[user_id].img_movie_later()
-
-    def img_movie_earlier(self, user_id):
-        return self.user_blendingvariableholder[user_id].img_movie_earlier()
-
-    def generate_movie(self, user_id, t_per_segment):
-        return self.user_blendingvariableholder[user_id].generate_movie(t_per_segment)
+for _name in ("preview_img_selected", "movie_img_selected", "compute_imgs", "get_list_images_movie", "init_new_movie", "write_json",
+              "add_image_to_video", "img_movie_delete", "img_movie_later", "img_movie_earlier", "generate_movie"):
+    setattr(MultiUserRouter, _name, _forward(_name))
+del _name
 
 
 def launch_ui(mur: MultiUserRouter, nmb_preview_images: int = 4, server_name: Optional[str] = None, launch: bool = True):
