@@ -31,6 +31,17 @@
         }                                                                                  \
     } while (0)
 
+// GB_PREFETCH study: touch a weight matrix from a second stream while the previous GEMM runs (does a weight that already sits in the
+// Infinity Cache / an L2 make the launch-bound small-M GEMMs faster?).  16 B per lane, the sum goes nowhere.
+__global__ void prefetch_touch_kernel(const uint4* __restrict__ w, long n16, unsigned* sink) {
+    unsigned acc = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long)gridDim.x * blockDim.x) {
+        const uint4 v = w[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345679u) *sink = acc;
+}
+
 struct Shape { int M, N, K; int geglu; int epi; const char* what; };     // epi: 0 none, 1 bias, 2 bias + residual
 
 static const Shape B17[] = {
@@ -97,6 +108,16 @@ int main(int argc, char** argv) {
     }
     const int NV = (int)variants.size();
     const bool nocheck = getenv("GB_NOCHECK") != nullptr, norocblas = getenv("GB_NOROCBLAS") != nullptr;
+    // GB_WARM=1: every launch reads the SAME weight copy (resident in L2 / Infinity Cache: the bound a perfect prefetcher could reach);
+    // GB_PREFETCH=<blocks>: weights stay cold, but copy i + 1 is touched by <blocks> x 256 threads on a second stream while GEMM i runs
+    const bool warm = getenv("GB_WARM") != nullptr;
+    const int prefetch_blocks = getenv("GB_PREFETCH") ? atoi(getenv("GB_PREFETCH")) : 0;
+    hipStream_t pstream;
+    CK(hipStreamCreate(&pstream));
+    std::vector<hipEvent_t> pev(64);
+    for (auto& e : pev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    unsigned* psink;
+    CK(hipMalloc(&psink, 4));
     setvbuf(stdout, nullptr, _IOLBF, 0);
 
     hipStream_t stream;
@@ -110,7 +131,8 @@ int main(int argc, char** argv) {
     void* zero_page;
     CK(hipMalloc(&zero_page, 256));
     CK(hipMemset(zero_page, 0, 256));
-    printf("# lb_gemm_f16 variants vs the automatic choice (bit-identity) and rocBLAS gemm_ex; cold weights, median of %d rounds\n", rounds);
+    printf("# lb_gemm_f16 variants vs the automatic choice (bit-identity) and rocBLAS gemm_ex; %s weights%s, median of %d rounds\n",
+           warm ? "WARM (one copy)" : "cold", prefetch_blocks > 0 ? " + next copy touched from a second stream" : "", rounds);
 
     for (const Shape& s : shapes) {
         const long wbytes = (long)s.N * s.K * 2;
@@ -198,14 +220,26 @@ int main(int argc, char** argv) {
                 if (v == NV && norocblas) continue;
                 CK(hipEventRecord(e0, stream));
                 for (int i = 0; i < nw; ++i) {
-                    if (v < NV) run(variants[v], i, dC);
-                    else
+                    if (prefetch_blocks > 0 && v < NV) {       // copy i + 1 is touched while GEMM i runs (never more than one launch ahead)
+                        if (i > 0) CK(hipStreamWaitEvent(pstream, pev[(i - 1) % 64], 0));
+                        hipLaunchKernelGGL(prefetch_touch_kernel, dim3(prefetch_blocks), dim3(256), 0, pstream,
+                                           (const uint4*)dW[(i + 1) % nw], wbytes / 16, psink);
+                    }
+                    if (v < NV) {
+                        run(variants[v], warm ? 0 : i, dC);
+                        if (prefetch_blocks > 0) CK(hipEventRecord(pev[i % 64], stream));
+                    } else
+                        rocblas_gemm_ex(rb, rocblas_operation_transpose, rocblas_operation_none, s.N, s.M, s.K, &alpha, dW[warm ? 0 : i], rocblas_datatype_f16_r,
+                                        s.K, dA, rocblas_datatype_f16_r, s.K, &beta, dC, rocblas_datatype_f16_r, s.N, dC, rocblas_datatype_f16_r, s.N,
+                                        rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+                    if (false)
                         rocblas_gemm_ex(rb, rocblas_operation_transpose, rocblas_operation_none, s.N, s.M, s.K, &alpha, dW[i], rocblas_datatype_f16_r,
                                         s.K, dA, rocblas_datatype_f16_r, s.K, &beta, dC, rocblas_datatype_f16_r, s.N, dC, rocblas_datatype_f16_r, s.N,
                                         rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
                 }
                 CK(hipEventRecord(e1, stream));
                 CK(hipEventSynchronize(e1));
+                if (prefetch_blocks > 0) CK(hipStreamSynchronize(pstream));
                 float ms = 0;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 if (r > 0) us[v].push_back(ms * 1e3f / nw);           // (round 0 = warm-up)
