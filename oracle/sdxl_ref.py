@@ -5,10 +5,15 @@ executes through ``diffusers==0.25.0`` / ``lpips==0.1.4`` (both absent from /roo
 from this image; pinned in /root/reference/requirements.txt:1,3).  Only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
 
-PARITY UNPINNED for this file: the reference ships no tests, golden vectors or weights for the
-UNet / VAE / LPIPS arithmetic, and the third-party sources are not available
-here; the restatement follows the published architecture (validated by the
-exact parameter counts 2,567,463,684 / 49,490,199 — see ``count_params``) and the call sites
+PARITY UNPINNED for the UNet, the schedulers' step arithmetic and LPIPS in this file: the reference
+ships no tests, golden vectors or weights for them, and the third-party sources
+are not available here; the restatement follows the published architecture (SURVEY.md Appendix B,
+validated by the exact parameter counts 2,567,463,684 / 49,490,199 — see ``count_params``).
+PINNED (round 6, tests/test_oracle_pins_cpu.py): ``vae_decode`` equals — same weights, fp32
+round-off — the latent-diffusion decoder that ``transformers`` ships as ``JanusVQVAEDecoder``
+(the module diffusers' ``AutoencoderKL.decoder`` was ported from; its extra lowest-level
+attention blocks emptied, as the SD autoencoders have none), at the tiny and at the full SDXL
+width; ``attention`` equals torch's ``scaled_dot_product_attention``.  Call sites restated:
   latentblending/diffusers_holder.py:330      scheduler.scale_model_input
   latentblending/diffusers_holder.py:336-344  pipe.unet(...)
   latentblending/diffusers_holder.py:356      scheduler.step
