@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (cfg 3 and the skewed-metric run) of the N = 1 record")
+    ap.add_argument("--torch-baseline", action="store_true",
+                    help="opt-in diagnostic instead of the metric: the oracle's PyTorch graph of the UNet step and the VAE decode executed on the "
+                         "SAME GPU through the vendor libraries (torch eager under autocast fp16: rocBLAS / hipBLASLt, MIOpen, torch SDPA), "
+                         "beside this repo's launch programs on the same weights and inputs")
     ap.add_argument("--no-materialise", action="store_true",
                     help="leave the returned frames in HBM (lazy PIL images) instead of copying them to host PIL images inside the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --rendezvous-only)")
@@ -389,6 +393,77 @@ def _physical_cores():
     except OSError:
         pass
     return len(seen) or (os.cpu_count() or 1)
+
+
+def same_gpu_torch_baseline(pipe, unet_w, vae_w, device):
+    """Opt-in (`--torch-baseline`): what the VENDOR STACK makes of the same arithmetic on the same MI355X.  The oracle's PyTorch graph
+    (oracle/sdxl_ref.py: the restatement of the diffusers UNet / VAE the reference calls at diffusers_holder.py:336,135) runs on the GPU,
+    eager, under torch.autocast(float16): linear / conv / matmul in fp16 on rocBLAS / hipBLASLt / MIOpen, norms and softmax in fp32 as
+    autocast leaves them, attention through torch's fused scaled_dot_product_attention (the oracle's explicit softmax(QK^T)V would
+    understate the stack), convolutions in MIOpen's immediate mode (what an untuned diffusers pipeline gets).  Beside it: this repo's
+    launch programs (hipGraph replay) on the same weights, batch and resolution.  The oracle is the yardstick here, as in cpu_baseline -
+    never part of the product path."""
+    import torch.nn.functional as F
+    from oracle import sdxl_ref as R
+    dev = torch.device(device)
+    ucfg, vcfg = R.UNetCfg(sample_size=64), R.VAECfg()
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    def sdpa(q, k, v, heads):
+        B, Sq, C = q.shape
+        d = C // heads
+        sp = lambda t: t.view(B, -1, heads, d).transpose(1, 2)
+        return F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, Sq, C)
+
+    out = {"how": "oracle/sdxl_ref.py graph on the same GPU: torch eager, autocast fp16 (rocBLAS / hipBLASLt GEMMs, MIOpen convs in immediate "
+                  "mode, torch SDPA attention; norms / softmax fp32 as autocast keeps them); ours = hipGraph replay of the launch programs"}
+    keep_attention = R.attention
+    R.attention = sdpa
+    try:
+        with torch.no_grad():
+            wu = {k: v.to(dev) for k, v in unet_w.items()}
+            for B in (17, 2):
+                g = torch.Generator().manual_seed(B)
+                x = torch.randn(B, 4, 64, 64, generator=g).half().to(dev)
+                ctx = torch.randn(B, 77, 2048, generator=g).half().to(dev)
+                te = torch.randn(B, 1280, generator=g).half().to(dev)
+                ids = torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]] * B, device=dev)
+                t = torch.tensor(499.0, device=dev)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    ms_t = timed(lambda: R.unet_forward(ucfg, wu, x, t, ctx, te, ids), 3)
+                prog = pipe.unet_program(B, 64)
+                prog.set_conditioning(ctx, te, ids)
+                prog.forward(x, torch.full((B,), 499.0))
+                prog.enable_graphs()
+                ms_o = timed(prog.prog_step.launch, 5)
+                out[f"unet_step_B{B}_ms"] = {"torch_eager_vendor_stack": round(ms_t, 2), "this_repo": round(ms_o, 2), "ratio": round(ms_t / ms_o, 2)}
+            del wu
+            torch.cuda.empty_cache()
+            wv = {k: v.to(dev) for k, v in vae_w.items()}
+            for B in (17,):
+                z = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(3)).half().to(dev)
+                with torch.autocast("cuda", dtype=torch.float16):
+                    ms_t = timed(lambda: R.vae_decode(vcfg, wv, z), 2)
+                ms32 = timed(lambda: R.vae_decode(vcfg, wv, z), 1)      # fp32: what diffusers' force_upcast VAE (SDXL's default) runs
+                vp = pipe.vae_program(B, 64)
+                vp.decode(z)
+                vp.prog.instantiate()
+                ms_o = timed(vp.prog.launch, 5)
+                out[f"vae_decode_B{B}_ms"] = {"torch_eager_vendor_stack": round(ms_t, 2), "torch_eager_fp32_force_upcast": round(ms32, 2),
+                                               "this_repo": round(ms_o, 2), "ratio": round(ms_t / ms_o, 2)}
+    finally:
+        R.attention = keep_attention
+    return out
 
 
 def cpu_baseline(unet_w, vae_w, census):
@@ -720,7 +795,7 @@ def _run():
     # seeded synthetic SDXL weights from the product's own provider; rank 0 keeps the fp32 copies so
     # that the cpu_baseline leg can time the oracle on exactly the same parameters
     base = args.config == "cfg3"
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not base
+    want_cpu = rank == 0 and world == 1 and (args.torch_baseline or not args.no_cpu_baseline) and not base
     t0 = time.perf_counter()
     # LB_SYNTH_CACHE=<dir>: keep the generated (seeded, fp16-rounded) tensors in a scratch file between the several
     # processes of a profiling session - the same values, a few seconds instead of a minute of CPU random draws
@@ -734,6 +809,10 @@ def _run():
         unet_prov.save_cache(); vae_prov.save_cache()
     t_weights = time.perf_counter() - t0
     unet_w, vae_w = unet_prov.state, vae_prov.state
+    if args.torch_baseline:
+        assert world == 1 and not base, "--torch-baseline: one GPU, cfg 2 model sizes"
+        return {"metric": "diagnostic: vendor-stack (torch eager) time of the UNet step / VAE decode on the same GPU, beside this repo's programs",
+                "value": None, "unit": "ms", "n_gpus": 1, "same_gpu_torch_baseline": same_gpu_torch_baseline(pipe, unet_w, vae_w, f"cuda:{local_rank}")}
     farm = None
     if world > 1:
         from latentblending_amd.dist import BranchFarm

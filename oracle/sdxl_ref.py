@@ -464,7 +464,7 @@ def ancestral_sigmas(s_from: float, s_to: float) -> Tuple[float, float]:
 def sinusoid(values: Tensor, dim: int) -> Tensor:
     """diffusers ``Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)``: [cos | sin]."""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=values.device) / half)
     ang = values.float()[:, None] * freqs[None]
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
