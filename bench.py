@@ -305,7 +305,8 @@ def roofline_blocks(prof, launch_counts, device):
                          "library's 19.2 / 33.8 / 95.7; still 10-14 % behind it on the two K = 1280 single-partial-round shapes (its stream-K tiles "
                          "balance 230 tiles over 256 CUs); PMC of the halo conv (profiles/r05_halo_pmc_lean_epilogue.json): matrix pipe 51 % busy on "
                          "the VAE's big shapes, 65 % on the UNet's deep-K shape, 0.5 LDS instructions per MFMA, LDS pipe 25 % busy - wave time goes "
-                         "to vmcnt / barrier waits",
+                         "to vmcnt / barrier waits; the 3x3 convolutions against MIOpen's best solver on the same operands (torch conv2d, find mode; "
+                         "profiles/r06_conv_vs_miopen.txt): the halo-tile kernel is 1.2 - 1.7x the vendor library on every shape of the programs",
         "traffic_unit": "HBM-side bytes per GEMM/conv launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                         "command committed in profiles/; null if absent)",
         "algorithmic_bytes_per_launch": prof["gemm_bytes"] / max(prof["gemm_launches"], 1),
@@ -327,6 +328,9 @@ def roofline_blocks(prof, launch_counts, device):
                    "attn_fwd_d512_kernel (VAE mid block), in situ", "bound": "mfma", "achieved": a,
          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / MFMA_F16_PEAK_TFLOPS,
          "measured_by": "hipEvents between the ops of an eager replay, this run (PMC of the kernels: profiles/r06_attention_pmc.json)",
+         "headroom_note": "issue-bound on the softmax's VALU work at 64-wide heads, not on the matrix pipe (PMC); against the vendor's fused attention on "
+                          "the same operands (torch SDPA on ROCm, profiles/r06_attn_vs_sdpa.txt): self-attention S = 256 15.0 vs 27.9 us, S = 1024 71.1 vs "
+                          "103.4 us, cross-attention 11.3 vs 18.6 us, VAE d = 512 1.00 vs 2.54 ms - 1.4 - 2.6x the library",
          "per_transition": {"tflop": prof["attn_flops"] / 1e12, "ms": prof["attn_ms"], "launches": prof["attn_launches"],
                             "self_TFLOPs": _tf(prof["attn_self_flops"], prof["attn_self_ms"]), "self_ms": prof["attn_self_ms"],
                             "cross_TFLOPs": _tf(prof["attn_cross_flops"], prof["attn_cross_ms"]), "cross_ms": prof["attn_cross_ms"]}},
