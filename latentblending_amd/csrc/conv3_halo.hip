@@ -47,6 +47,11 @@
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+#ifndef LB_HALO_LEAN_ADDR      // round 6: leaner address arithmetic in the step loop (see the kernel); 0 = the forms of rounds 2-5 (A/B builds)
+#define LB_HALO_LEAN_ADDR 1
+#endif
+#define LB_HALO_LEAN_ADDR_DEFAULT_ON (LB_HALO_LEAN_ADDR != 0)
+
 template <int N> __device__ __forceinline__ void halo_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
@@ -92,7 +97,10 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     f16* const halo0 = lds;
     f16* const wring = lds + 2 * HRP * 64;              // 4 slots of BN rows
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (wave-uniform by construction: through readfirstlane, so that everything derived from it - the LDS destination of every direct-to-LDS
+    //  request (M0), the `wave < EXTRA` tests - is scalar arithmetic instead of a VALU chain + v_readfirstlane per request)
+    const int wave = LB_HALO_LEAN_ADDR_DEFAULT_ON ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int g = lane >> 4, l16 = lane & 15;
 
@@ -152,12 +160,17 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
             h_off[j] = ok ? ((long)(t.b * p.Hin + y) * p.Win + x) * p.ldx + cl * 8 : -1;
         }
     };
-    // weights: thread stages rows (tid>>3) + 64 i of the BN x 64 tile
+    // weights: thread stages rows (tid>>3) + 64 i of the BN x 64 tile.  Round 6 (LB_HALO_LEAN_ADDR): a 32-bit BYTE offset per lane on a
+    // wave-uniform base (tap / chunk position: scalar), and no mask - rows past N re-read row N - 1 (their output columns are never
+    // stored, and every column's accumulator is its own), requests past the end of the block's work re-read the last tap / chunk (into
+    // ring slots nobody reads again) - instead of a 64-bit address + two selects against the zero page per request.
     long w_off[WI];
+    unsigned w_off32[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
         const int n = n0 + (tid >> 3) + i * 64;
         w_off[i] = n < p.N ? (long)n * p.ldw + cl * 8 : -1;
+        w_off32[i] = (unsigned)(((long)(n < p.N ? n : p.N - 1) * p.ldw + cl * 8) * 2);
     }
 
 #ifdef LB_STUDY_BUILD
@@ -172,9 +185,18 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
     auto issue_weight = [&](int i, int chunk, bool exists, int tap, int slot) {
+        f16* dst = wring + slot * (BN * 64) + (wave * 8 + i * 64) * 64;
+        if constexpr (LB_HALO_LEAN_ADDR) {
+            if (!(study & 4)) {
+                // (exists == false: chunk / tap are those of a request past the end: any staged bytes will do - the address stays inside W
+                //  because the caller wraps them to chunk 0 / a tap < NTAP)
+                const char* base = reinterpret_cast<const char*>(Wp) + ((long)tap * p.Cin + (long)chunk * 64) * 2;        // wave-uniform
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + (size_t)w_off32[i]), (lptr_t)dst, 16, 0, 0);
+                return;
+            }
+        }
         const bool live = w_off[i] >= 0 && exists && !(study & 4);
         const lb_half* src = live ? Wp + w_off[i] + (long)tap * p.Cin + (long)chunk * 64 : zero;
-        f16* dst = wring + slot * (BN * 64) + (wave * 8 + i * 64) * 64;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
     };
 
@@ -196,10 +218,23 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
 
     auto read_frags = [&](const f16* hb, const f16* wb, int shift, int s, f16x8 (&af)[TM], f16x8 (&wf)[TN]) {
         const int chunk = s * 4 + g;
+        if constexpr (LB_HALO_LEAN_ADDR && TW == 32) {
+            // TW = 32: the lane's pixels i and i + 1 (i even) are 16 pixels apart in ONE image row: halo rows r and r + 16, same
+            // swizzle key (r & 7) - one address per pair, the second fragment 16 rows = 2 KiB further on (an instruction offset)
+            static_assert(TM == 4, "pairs (0, 1) and (2, 3)");
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int r = hbase[i] + shift;
-            af[i] = *reinterpret_cast<const f16x8*>(hb + r * 64 + ((chunk ^ (r & 7)) << 3));
+            for (int i = 0; i < TM; i += 2) {
+                const int r = hbase[i] + shift;
+                const f16* a = hb + r * 64 + ((chunk ^ (r & 7)) << 3);
+                af[i] = *reinterpret_cast<const f16x8*>(a);
+                af[i + 1] = *reinterpret_cast<const f16x8*>(a + 16 * 64);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = hbase[i] + shift;
+                af[i] = *reinterpret_cast<const f16x8*>(hb + r * 64 + ((chunk ^ (r & 7)) << 3));
+            }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
