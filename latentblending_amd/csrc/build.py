@@ -17,7 +17,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 
 # per-source extra flags (see the header comment of the file for the reason)
 _ATTN_FLAGS = ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
-EXTRA_FLAGS = {"attn.hip": _ATTN_FLAGS, "attn512.hip": _ATTN_FLAGS}
+# gemm_glds.hip (round 6): with the K loop instantiated twice (lean / general requests) hipcc parks the accumulators of the small tiles in
+# AGPRs and rotates them through v_accvgpr_read / _mov / _write every K-tile (24-92 extra instructions per tile); the VGPR form keeps them put
+EXTRA_FLAGS = {"attn.hip": _ATTN_FLAGS, "attn512.hip": _ATTN_FLAGS, "gemm_glds.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():

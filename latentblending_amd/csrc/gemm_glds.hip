@@ -14,10 +14,14 @@
 //                                                reading stage (t-1) % S, which is refilled next
 //   issue tile t+S-1 ; ds_read + MFMA on stage t % S
 // i.e. ONE barrier per K-tile and never a vmcnt(0) in the steady state.
+#include <type_traits>
 #include "lb_common.h"
 #include "lb_gemm.h"
 
 #define BK 64
+#ifndef LB_GLDS_LEAN        // round 6: lean request addressing (see the kernel); 0 = the forms of rounds 1-5 (A/B builds)
+#define LB_GLDS_LEAN 1
+#endif
 // Ablation builds for tools/gemm_ablate.py ONLY (never the shipped library): 1 = no global->LDS
 // requests, 2 = no LDS reads / MFMAs, 3 = MFMAs on register operands (no LDS reads).
 #ifndef LB_ABLATE
@@ -84,7 +88,10 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
     const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT) : 0;      // (wave-uniform)
     const int tid = KG > 1 ? (int)threadIdx.x - kgrp * NT : (int)threadIdx.x;
     f16* const lds = lds_all + kgrp * (S * STAGE);
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    // (wave-uniform by construction: through readfirstlane, so that the LDS destination of every direct-to-LDS request (M0) is scalar
+    //  arithmetic instead of a VALU chain + v_readfirstlane per request - round 6, LB_GLDS_LEAN)
+    const int wave = LB_GLDS_LEAN ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int g = lane >> 4, l16 = lane & 15;
 
@@ -161,11 +168,63 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
     const lb_half* zero = reinterpret_cast<const lb_half*>(p.zero_page);
     const int hin_eff = p.Hin << p.ups, win_eff = p.Win << p.ups;
 
+    // ---- round 6: LEAN requests for plain / GEGLU GEMMs whose K is a whole number of K-tiles (every Linear of the UNet / CLIP programs) ----
+    // A request used to cost a 64-bit address, two selects against the zero page and a VALU chain for M0: 75 instructions around the 8 MFMAs
+    // of a 64x64 K-tile, 110 around the 24 of the 192x128 one - and the launch-bound B <= 4 GEMMs run their K-tiles as ONE dependent chain per
+    // wave.  Lean form (gemm_pp.hip's): a 32-bit BYTE offset per lane and request on a wave-uniform base that carries the K position (scalar),
+    // no masks - rows past M / N re-read the last row (their accumulator rows / columns are never stored: every output element has its own
+    // accumulator), tiles requested past the block's K range re-read its last K-tile (into ring stages nobody reads again).  Not when a
+    // K-group would have to MULTIPLY a tile past the end (KG > 1 with an odd tile count: those must be zero tiles), not for convolutions
+    // (padding must read zeros), not for a ragged K.  Same bytes staged for everything that is stored: bit-identical.
+    constexpr bool LEAN_OK = LB_GLDS_LEAN && !CONV && !(BM == 256 && BN == 256);
+    const bool lean = LEAN_OK && p.K % BK == 0 && nkt >= 1 && (KG == 1 || nkt % KG == 0) &&
+                      (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32) && !(p.reserved2_ & 16);
+    unsigned a_off32[AI], w_off32[WI];
+    if constexpr (LEAN_OK) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            int m = m0 + row0 + i * RPI;
+            m = m < p.M ? m : p.M - 1;
+            a_off32[i] = (unsigned)(((long)m * p.lda + cl * 8) * 2);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int tr = row0 + i * RPI;
+            int n;
+            if (GEGLU) {
+                const int sub = tr >> 4, half = p.N / 2;
+                int oc = n0 + (sub >> 1) * 16 + (tr & 15);
+                oc = oc < half ? oc : half - 1;
+                n = (sub & 1) * half + oc;
+            } else {
+                n = n0 + tr;
+            }
+            n = n < p.N ? n : p.N - 1;              // (also the staging rows past BN of a partial round: padding rows of the stage)
+            w_off32[i] = (unsigned)(((long)n * p.ldw + cl * 8) * 2);
+        }
+    }
+    // K-tile of this K-group the NEXT issue_tile stages, and the last one that exists (scalar)
+    int lean_kt = kt_begin + kgrp;
+    const int lean_kt_last = kt_begin + kgrp + ((nkt - 1 - kgrp) / KG) * KG;
+
     // request number idx (0..NL-1: AI rows of A, then WI rows of W) of the current K-tile into the ring
     // stage at `base` (branch-free: masked chunks read the zero page)
-    auto issue_one = [&](int idx, f16* base, bool k_ok) {
+    auto issue_one = [&](auto leanc, int idx, f16* base, bool k_ok) {
         const lb_half* src;
         f16* dst;
+        if constexpr (decltype(leanc)::value) {
+            const long kbyte = (long)(lean_kt < lean_kt_last ? lean_kt : lean_kt_last) * (BK * 2);        // scalar
+            if (idx < AI) {
+                src = reinterpret_cast<const lb_half*>(reinterpret_cast<const char*>(p.A) + kbyte + (size_t)a_off32[idx < AI ? idx : 0]);
+                dst = base + (wave * 8 + idx * RPI) * BK;
+            } else {
+                const int i = idx - AI;
+                src = reinterpret_cast<const lb_half*>(reinterpret_cast<const char*>(p.W) + kbyte + (size_t)w_off32[i < WI && i >= 0 ? i : 0]);
+                dst = base + BM * BK + (wave * 8 + i * RPI) * BK;
+            }
+            if (LB_ABLATE != 1) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            return;
+        }
         if (idx < AI) {
             const int i = idx;
             if (CONV) {
@@ -187,6 +246,7 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
     // advance this thread's K position (and conv tap state) by one K-tile
     auto advance_k = [&]() {
         kcur += BK * KG;
+        lean_kt += KG;
         if (CONV) {
             ci += BK;
             if (p.Cin >= BK) {
@@ -204,11 +264,11 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
             }
         }
     };
-    auto issue_tile = [&](int st) {
+    auto issue_tile = [&](auto leanc, int st) {
         f16* base = lds + st * STAGE;
         const bool k_ok = kcur < k_end;
 #pragma unroll
-        for (int idx = 0; idx < NL; ++idx) issue_one(idx, base, k_ok);
+        for (int idx = 0; idx < NL; ++idx) issue_one(leanc, idx, base, k_ok);
         advance_k();
     };
 
@@ -247,9 +307,12 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     };
 
+    // the prologue and the K loop, once per request form: `lean` is a block-uniform run-time fact, the two forms are separate loops (as
+    // one loop with the form tested per request hipcc computes BOTH addresses and selects)
+    auto main_loop = [&](auto leanc) {
     // ---- prologue: tiles 0 .. S-2 in flight ----
 #pragma unroll
-    for (int s = 0; s < S - 1; ++s) issue_tile(s);
+    for (int s = 0; s < S - 1; ++s) issue_tile(leanc, s);
 
     // One K-tile per iteration.  The NL requests of tile t+S-1 are NOT issued in one burst after the
     // barrier (all waves of a block would then sit in the VMEM issue queue together and start their
@@ -264,9 +327,9 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
         int refill = st - 1;
         if (refill < 0) refill += S;
         if (LB_ABLATE == 2) {
-            issue_tile(refill);
+            issue_tile(leanc, refill);
         } else if (LB_BURST || (CONV && WMW == 2)) {   // 4-wave conv tiles measured 3-6 % faster with the burst
-            issue_tile(refill);               // tile t+S-1 (masked to zeros past the end)
+            issue_tile(leanc, refill);               // tile t+S-1 (masked to zeros past the end)
             f16x8 af[TM], wf[TN];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -281,7 +344,7 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
             read_frags(st, 0, a0, w0);
 #pragma unroll
             for (int idx = 0; idx < NL; ++idx)
-                if (idx * 4 / NL == 0) issue_one(idx, base, k_ok);
+                if (idx * 4 / NL == 0) issue_one(leanc, idx, base, k_ok);
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a0, w0, 0, HM);
             read_frags(st, 1, a1, w1);
@@ -289,25 +352,32 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int idx = 0; idx < NL; ++idx)
-                if (idx * 4 / NL == 1) issue_one(idx, base, k_ok);
+                if (idx * 4 / NL == 1) issue_one(leanc, idx, base, k_ok);
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a0, w0, HM, TM);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int idx = 0; idx < NL; ++idx)
-                if (idx * 4 / NL == 2) issue_one(idx, base, k_ok);
+                if (idx * 4 / NL == 2) issue_one(leanc, idx, base, k_ok);
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a1, w1, 0, HM);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int idx = 0; idx < NL; ++idx)
-                if (idx * 4 / NL == 3) issue_one(idx, base, k_ok);
+                if (idx * 4 / NL == 3) issue_one(leanc, idx, base, k_ok);
             advance_k();
             if (LNA == 1) ln_accumulate<TM>(a1, ln_sum, ln_sq);
             __builtin_amdgcn_sched_barrier(0);
             mma_rows(a1, w1, HM, TM);
         }
         st = st + 1 == S ? 0 : st + 1;
+    }
+    };      // main_loop
+    if constexpr (LEAN_OK) {
+        if (lean) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+    } else {
+        main_loop(std::false_type{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the masked tail requests before exit/epilogue
 
