@@ -454,6 +454,7 @@ int lb_upconv_halo_eligible(const LbGemmParams& p) {
     if (p.Hout != p.Hin || p.Wout != p.Win || p.Cin % 64 != 0 || p.K != 4 * p.Cin) return 0;
     if (p.zero_page == nullptr || (p.flags & (LB_GEMM_GEGLU | LB_GEMM_TRANS_OUT)) || p.N % 4 != 0 || p.residual != nullptr) return 0;
     if (p.M % (p.Hin * p.Win) != 0) return 0;
+    if ((long)p.N * p.ldw * 2 >= (1l << 32)) return 0;         // (32-bit byte offsets into one parity's weight slab: LB_HALO_LEAN_ADDR)
     if (p.Win % 32 == 0 && p.Hin % 8 == 0) return 32;
     if (p.Win % 16 == 0 && p.Hin % 16 == 0) return 16;
     return 0;
@@ -485,6 +486,7 @@ int lb_conv3x3_halo_eligible(const LbGemmParams& p) {
     if (p.Hout != p.Hin || p.Wout != p.Win || p.Cin % 64 != 0 || p.K != 9 * p.Cin) return 0;
     if (p.zero_page == nullptr || (p.flags & LB_GEMM_GEGLU) || p.N % 4 != 0) return 0;
     if (p.M % (p.Hin * p.Win) != 0) return 0;
+    if ((long)p.N * p.ldw * 2 >= (1l << 32)) return 0;         // (32-bit byte offsets into the weight matrix: LB_HALO_LEAN_ADDR)
     if (p.Win % 32 == 0 && p.Hin % 8 == 0) return 32;
     if (p.Win % 16 == 0 && p.Hin % 16 == 0) return 16;
     return 0;
