@@ -50,7 +50,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #ifndef LB_HALO_LEAN_ADDR      // round 6: leaner address arithmetic in the step loop (see the kernel); 0 = the forms of rounds 2-5 (A/B builds)
 #define LB_HALO_LEAN_ADDR 1
 #endif
-#define LB_HALO_LEAN_ADDR_DEFAULT_ON (LB_HALO_LEAN_ADDR != 0)
 
 template <int N> __device__ __forceinline__ void halo_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -100,7 +99,7 @@ __global__ void __launch_bounds__(512) conv3x3_halo_kernel(const LbGemmParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     // (wave-uniform by construction: through readfirstlane, so that everything derived from it - the LDS destination of every direct-to-LDS
     //  request (M0), the `wave < EXTRA` tests - is scalar arithmetic instead of a VALU chain + v_readfirstlane per request)
-    const int wave = LB_HALO_LEAN_ADDR_DEFAULT_ON ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+    const int wave = LB_HALO_LEAN_ADDR ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int g = lane >> 4, l16 = lane & 15;
 

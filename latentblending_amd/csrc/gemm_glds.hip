@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(WMW * 128 * KG) gemm_f16_glds_kernel(const LbG
     // (padding must read zeros), not for a ragged K.  Same bytes staged for everything that is stored: bit-identical.
     constexpr bool LEAN_OK = LB_GLDS_LEAN && !CONV && !(BM == 256 && BN == 256);
     const bool lean = LEAN_OK && p.K % BK == 0 && nkt >= 1 && (KG == 1 || nkt % KG == 0) &&
-                      (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32) && !(p.reserved2_ & 16);
+                      (long)p.M * p.lda * 2 < (1l << 32) && (long)p.N * p.ldw * 2 < (1l << 32);
     unsigned a_off32[AI], w_off32[WI];
     if constexpr (LEAN_OK) {
 #pragma unroll
