@@ -915,7 +915,7 @@ def _run():
                                            "cfg4 (BASELINE configs[3], the config STATED for 8 GPUs)": "--gpus N --branches-total 64 --frontier 64: 64 mid "
                                            "branches in one round, 8 per rank at N = 8 (B = 2 + 8 batches: the anchors' two small steps are 1/5 "
                                            "of a rank's UNet time instead of 2/3 as in cfg 2 at N = 8)"},
-                       "expected_strong_scaling": "Amdahl-limited by design: the two B=2 anchor steps (2 x 10.9 ms of a 139 ms transition on one GPU, round 6) "
+                       "expected_strong_scaling": "Amdahl-limited by design: the two B=2 anchor steps (2 x 10.8 ms of a 135 ms transition on one GPU, round 6) "
                                                   "and the anchors' share of the B = 2 + G/N batches do not shard - about 2.3-2.5x at 8 GPUs for cfg 2 "
                                                   "(DESIGN.md section 5); --scaling weak (15 N branches) is the sharded regime"},
                    "census_per_transition": per_transition, "weights_gen_s": round(t_weights, 1),
