@@ -300,10 +300,10 @@ def roofline_blocks(prof, launch_counts, device):
                        "per op included: the conservative figure; the rocprofv3 kernel-duration figure of the committed run of the same command is in "
                        "profiles/r06_rocprof_summary.json and is ~5 % higher)",
         "headroom_note": "like-for-like against the vendor library (rocBLAS gemm_ex, no epilogue operands on either side; "
-                         "profiles/r06_gemm_bench_call2.txt, r05_gemm_bench_call4.txt): round 6 runs the 192x128 tile as 8 waves of 48x64 "
-                         "(every SIMD issues the same MFMA count): M 4352 x N 1280 at K 1280 / 2560 / 5120 = 21.9 / 34.0 / 64.4 us against the "
-                         "library's 19.2 / 33.8 / 95.7; still 10-14 % behind it on the two K = 1280 single-partial-round shapes (its stream-K tiles "
-                         "balance 230 tiles over 256 CUs); PMC of the halo conv (profiles/r05_halo_pmc_lean_epilogue.json): matrix pipe 51 % busy on "
+                         "profiles/r06_gemm_bench_final.txt): round 6 runs the 192x128 tile as 8 waves of 48x64 (every SIMD issues the same MFMA "
+                         "count) with lean request addressing: M 4352 x N 1280 at K 1280 / 2560 / 5120 = 20.3 / 35.1 / 64.1 us against the "
+                         "library's 19.2 / 35.6 / 97.6; ahead or within 3 % on 7 of 10 shapes of the programs, 4-10 % behind on q|k|v, the K = 1280 "
+                         "projection and the 640-wide GEGLU (single-partial-round grids: its stream-K tiles balance 230 tiles over 256 CUs); PMC of the halo conv (profiles/r05_halo_pmc_lean_epilogue.json): matrix pipe 51 % busy on "
                          "the VAE's big shapes, 65 % on the UNet's deep-K shape, 0.5 LDS instructions per MFMA, LDS pipe 25 % busy - wave time goes "
                          "to vmcnt / barrier waits; the 3x3 convolutions against MIOpen's best solver on the same operands (torch conv2d, find mode; "
                          "profiles/r06_conv_vs_miopen.txt): the halo-tile kernel is 1.2 - 1.7x the vendor library on every shape of the programs",
